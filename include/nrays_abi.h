@@ -1,0 +1,228 @@
+/*
+ * nrays_abi.h — C ABI of the MI355X-native replacement for nrays' per-pixel trace loop.
+ *
+ * This is the drop-in boundary for `scene::render` (reference src/scene.rs:29-36) and for the
+ * construction surface that feeds it (`Scene::new` src/scene.rs:119, `SceneNode::new`
+ * src/scene_node.rs:22-47, `Light::new` src/light.rs:16, `PhongMaterial::new`
+ * src/phong_material.rs:19-26).  A host written in any language (the reference is Rust) fills
+ * the POD descriptors below once per scene and calls `nrays_scene_create`; every later
+ * `scene::render` becomes one `nrays_render` call.  INTEGRATION.md shows the Rust `extern "C"`
+ * binding a maintainer would add.
+ *
+ * Rules of the boundary
+ *   - plain C, `extern "C"`, POD structs only (`#[repr(C)]` on the Rust side), no exceptions;
+ *   - the library copies everything it needs inside `nrays_scene_create`; the caller keeps
+ *     ownership of every pointer it passes;
+ *   - every entry point returns 0 (NRAYS_OK) or a negative NraysStatus; it never aborts
+ *     (the reference panics / silently swallows thread panics, src/scene.rs:111 — not reproduced);
+ *   - `nrays_last_error()` returns a thread-local, NUL-terminated description of the last failure.
+ *
+ * The same descriptors are consumed by the CPU oracle (oracle/nrays_oracle.c), which is test
+ * infrastructure and is NOT part of this library.
+ */
+#ifndef NRAYS_ABI_H
+#define NRAYS_ABI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NRAYS_ABI_VERSION 1
+
+typedef enum NraysStatus {
+    NRAYS_OK = 0,
+    NRAYS_ERR_BAD_ARG = -1,        /* NULL pointer, ray_per_pixel == 0 (src/scene.rs:37), bad index */
+    NRAYS_ERR_HIP = -2,            /* a HIP runtime call failed */
+    NRAYS_ERR_OOM = -3,            /* host or device allocation failed */
+    NRAYS_ERR_UNSUPPORTED = -4,    /* e.g. mesh vertices that are not f32-exact */
+    NRAYS_ERR_NO_DEVICE = -5,      /* no gfx950 device visible to the process */
+    NRAYS_ERR_QUEUE_OVERFLOW = -6  /* continuation-ray queue capacity exceeded */
+} NraysStatus;
+
+/* Shapes the loader can construct (examples/loader3d.rs:593-695). */
+typedef enum NraysShapeKind {
+    NRAYS_SHAPE_BALL = 0,     /* params[0] = radius                      (loader3d.rs:601) */
+    NRAYS_SHAPE_CUBOID = 1,   /* params[0..2] = half extents             (loader3d.rs:612) */
+    NRAYS_SHAPE_CYLINDER = 2, /* params[0] = half height, params[1] = radius, axis = local Y (:623) */
+    NRAYS_SHAPE_CAPSULE = 3,  /* params[0] = half height, params[1] = radius               (:634) */
+    NRAYS_SHAPE_CONE = 4,     /* params[0] = half height, params[1] = radius, apex at +Y   (:645) */
+    NRAYS_SHAPE_PLANE = 5,    /* params[0..2] = unit normal, through the local origin      (:656) */
+    NRAYS_SHAPE_TRIMESH = 6   /* mesh_id selects an NraysMesh                              (:695) */
+} NraysShapeKind;
+
+/* Material implementations that can cross the boundary (src/material.rs:6-17). */
+typedef enum NraysMaterialKind {
+    NRAYS_MAT_PHONG = 0,  /* src/phong_material.rs:9-152 */
+    NRAYS_MAT_NORMAL = 1, /* src/normal_material.rs:5-22 */
+    NRAYS_MAT_UV = 2      /* src/uv_material.rs:6-28 */
+} NraysMaterialKind;
+
+typedef enum NraysTexelFormat {
+    NRAYS_TEXEL_RGBA8 = 0,  /* 4 x u8; sampled as `u8 as f32 / 255.0` (src/texture2d.rs:111-162) */
+    NRAYS_TEXEL_RGBA32F = 1 /* 4 x f32, the reference's own in-memory form (Point4<f32>) */
+} NraysTexelFormat;
+
+typedef enum NraysInterpolation { NRAYS_INTERP_BILINEAR = 0, NRAYS_INTERP_NEAREST = 1 } NraysInterpolation;
+typedef enum NraysOverflow { NRAYS_OVERFLOW_WRAP = 0, NRAYS_OVERFLOW_CLAMP = 1 } NraysOverflow;
+
+/* src/light.rs:8-23.  `racsample` is already floor(sqrt(nsample)) (light.rs:20). */
+typedef struct NraysLight {
+    double pos[3];
+    double radius;
+    uint32_t racsample;
+    float color[3];
+} NraysLight;
+
+/* src/texture2d.rs:10-76.  Row 0 is the BOTTOM row of the image: the Y flip of
+ * texture2d.rs:99-107 has already been applied by whoever decoded the file, and so has the
+ * depth/opacity decode of :109-177 (opaque -> (r,g,b,1); opacity map -> (1,1,1,a)). */
+typedef struct NraysTexture {
+    uint32_t width;
+    uint32_t height;
+    uint32_t format;   /* NraysTexelFormat */
+    uint32_t interp;   /* NraysInterpolation */
+    uint32_t overflow; /* NraysOverflow */
+    uint32_t reserved;
+    const void* texels; /* width*height texels, row-major, index y*width + x (texture2d.rs:204) */
+} NraysTexture;
+
+/* src/phong_material.rs:9-26 for PHONG; the colour fields are ignored for NORMAL / UV. */
+typedef struct NraysMaterial {
+    uint32_t kind; /* NraysMaterialKind */
+    float ambiant[3];
+    float diffuse[3];
+    float specular[3];
+    float shininess;
+    int32_t texture_id;       /* index into textures, or -1 */
+    int32_t alpha_texture_id; /* index into textures, or -1 */
+} NraysMaterial;
+
+/* ncollide3d TriMesh::new(points, indices, uvs) as called at examples/loader3d.rs:695.
+ * Several meshes may alias the same `vertices` / `uvs` arrays (one SceneNode per OBJ group,
+ * each holding the whole vertex array and only its faces, loader3d.rs:690-695). */
+typedef struct NraysMesh {
+    uint32_t num_vertices;
+    uint32_t num_triangles;
+    const double* vertices;  /* 3*num_vertices, local space; must be f32-exact (obj.rs:197-205 parses f32) */
+    const double* uvs;       /* 2*num_vertices or NULL */
+    const uint32_t* indices; /* 3*num_triangles */
+} NraysMesh;
+
+/* One SceneNode (src/scene_node.rs:8-47).  The transform is given as the loader builds it:
+ * Isometry3::new(translation, axis_angle) (examples/loader3d.rs:546-552), i.e. `axis_angle` is a
+ * scaled-axis rotation in RADIANS (|axis_angle| = angle), not Euler angles. */
+typedef struct NraysNode {
+    uint32_t shape_kind; /* NraysShapeKind */
+    uint32_t solid;      /* 0/1, scene_node.rs:13 */
+    double params[3];
+    double translation[3];
+    double axis_angle[3];
+    float refl_mix;
+    float refl_atenuation;
+    float alpha;
+    float reserved0;
+    double refr_coeff;
+    uint32_t material_id;
+    int32_t mesh_id; /* for NRAYS_SHAPE_TRIMESH, else -1 */
+} NraysNode;
+
+/* Everything `Scene::new(nodes, lights, background)` receives (src/scene.rs:119-133). */
+typedef struct NraysSceneDesc {
+    float background[3];
+    uint32_t num_lights;
+    const NraysLight* lights;
+    uint32_t num_materials;
+    const NraysMaterial* materials;
+    uint32_t num_textures;
+    const NraysTexture* textures;
+    uint32_t num_meshes;
+    const NraysMesh* meshes;
+    uint32_t num_nodes;
+    const NraysNode* nodes;
+} NraysSceneDesc;
+
+/* Arguments of scene::render (src/scene.rs:29-36) plus extensions whose zero value preserves the
+ * reference behaviour. */
+typedef struct NraysRenderParams {
+    uint32_t width;           /* resolution.x */
+    uint32_t height;          /* resolution.y */
+    uint32_t ray_per_pixel;   /* must be > 0 (scene.rs:37) */
+    uint32_t max_depth;       /* 0 = energy rule only (scene.rs:204); else extra cap on trace depth.
+                                 A hard safety cap of 64 generations always applies (unbounded
+                                 refraction recursion in the reference, scene.rs:246). */
+    double window_width;      /* AA jitter window in pixels (scene.rs:75) */
+    double camera_eye[3];
+    double inv_proj_view[16]; /* (P*V)^-1, COLUMN-major as nalgebra stores Matrix4 (loader3d.rs:77-79) */
+    uint64_t seed;            /* counter-based RNG seed (reference RNG is OS-seeded, scene.rs:75) */
+    /* Framebuffer tiling (multi-GPU): rows are grouped in bands of `band_rows`; band b is rendered
+     * iff b % band_owners == band_owner.  band_rows == 0 renders the whole frame.  The output of a
+     * tiled render is the compact buffer of the owner's bands in increasing order. */
+    uint32_t band_rows;
+    uint32_t band_owner;
+    uint32_t band_owners;
+    uint32_t reserved;
+} NraysRenderParams;
+
+/* Counters of the last render of a scene (or of an oracle render).  A "ray" is one BVT query
+ * (`world.best_first_search`, src/scene.rs:153,166). */
+typedef struct NraysStats {
+    uint64_t rays_primary;    /* scene.rs:89 */
+    uint64_t rays_reflection; /* scene.rs:209 */
+    uint64_t rays_refraction; /* scene.rs:246 */
+    uint64_t rays_shadow;     /* scene.rs:153 */
+    uint64_t node_tests;      /* AABB tests (TLAS + BLAS); filled by instrumented renders only */
+    uint64_t tri_tests;       /* ray/triangle tests */
+    uint64_t prim_tests;      /* analytic primitive / instance tests */
+    uint64_t hit_records;     /* node + material records fetched at accepted hits */
+    uint64_t tex_samples;     /* texture samples (4 taps each when bilinear) */
+    uint32_t generations;     /* continuation generations executed */
+    uint32_t instrumented;    /* 1 if the traversal counters above are valid */
+    double kernel_ms_primary; /* GPU time of the primary kernel (HIP events) */
+    double kernel_ms_total;   /* GPU time of the whole render, first launch to last */
+} NraysStats;
+
+typedef struct NraysScene NraysScene; /* opaque */
+
+/* Builds the device-resident scene on the CURRENT HIP device of the calling thread: flattens the
+ * nodes, builds the BVHs, uploads.  Replaces Scene::new + BVT::new_balanced (src/scene.rs:119-133). */
+int nrays_scene_create(const NraysSceneDesc* desc, NraysScene** out_scene);
+
+/* Replaces scene::render (src/scene.rs:29-116).  `out_rgb` is HOST memory, caller-allocated,
+ * rows*width*3 floats, row-major, index (i + j*width)*3 (scene.rs:104), where rows = height for an
+ * untiled render and nrays_tile_rows(params) for a tiled one.  Blocking. */
+int nrays_render(NraysScene* scene, const NraysRenderParams* params, float* out_rgb);
+
+/* Same, but `out_rgb_device` is DEVICE memory on the scene's device and the work is enqueued on
+ * `hip_stream` (a hipStream_t, NULL = default stream) without a final synchronisation unless the
+ * scene needs host-side generation control (transparent scenes). */
+int nrays_render_device(NraysScene* scene, const NraysRenderParams* params, float* out_rgb_device,
+                        void* hip_stream);
+
+/* As nrays_render_device, with the traversal counters of NraysStats collected (slower). */
+int nrays_render_device_instrumented(NraysScene* scene, const NraysRenderParams* params,
+                                     float* out_rgb_device, void* hip_stream);
+
+/* Number of rows in the compact output buffer of a (possibly tiled) render. */
+uint32_t nrays_tile_rows(const NraysRenderParams* params);
+
+/* Un-permutes `band_owners` gathered compact tile buffers (concatenated in owner order, each
+ * nrays_tile_rows*width*3 floats) into one row-major frame.  Device pointers. */
+int nrays_untile_device(const float* gathered, float* out_rgb_device, uint32_t width, uint32_t height,
+                        uint32_t band_rows, uint32_t band_owners, void* hip_stream);
+
+/* Synchronises with the last render of `scene` and returns its counters. */
+int nrays_get_stats(NraysScene* scene, NraysStats* out_stats);
+
+void nrays_scene_destroy(NraysScene* scene);
+
+const char* nrays_last_error(void);
+
+uint32_t nrays_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* NRAYS_ABI_H */
