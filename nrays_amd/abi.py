@@ -123,6 +123,11 @@ def load_hip_lib():
     if not os.path.exists(HIP_LIB_PATH):
         raise ImportError("libnrays_hip.so is not built (%s missing); run `python -c 'import __graft_entry__ as g; "
                           "g.build()'` — the nrays_amd product path has no CPU fallback" % HIP_LIB_PATH)
+    # torch bundles its own libamdhip64.so (SONAME libamdhip64.so.7).  It must be loaded FIRST so that
+    # this library's NEEDED libamdhip64.so.7 binds to the same HIP runtime; two runtimes in one process
+    # cannot both own the GPU ("no HIP device visible").  torch is plumbing here: device memory,
+    # streams and torch.distributed.
+    import torch  # noqa: F401
     lib = C.CDLL(HIP_LIB_PATH)
     for name, (res, args) in HIP_SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the export is missing

@@ -1,0 +1,145 @@
+// device_types.h — HBM-resident layout of a flattened nrays scene (shared by host flattening code
+// and the gfx950 kernels).  See DESIGN.md §"Data layout in HBM".
+#pragma once
+#include <stdint.h>
+
+namespace nrays {
+
+// One BVH2 node holding BOTH child boxes (64 B = 4 x dwordx4).  A fetch of one node pays for two
+// AABB tests; bounds are f32 rounded OUTWARD from the f64 geometry, so an f64 slab test against
+// them is a superset of the reference's f64 test (ncollide AABB::toi_with_ray, src/scene.rs:276).
+// child >= 0: index of an internal node; child < 0: leaf, ~child = (first << 3) | (count - 1) for
+// triangle leaves (BLAS) and ~child = instance index for TLAS leaves.  An absent child has an
+// inverted box (min = +inf, max = -inf) and child = kEmptyChild.
+struct BvhNode {
+    float lmin[3], lmax[3];
+    float rmin[3], rmax[3];
+    int32_t left, right;
+    uint32_t pad[2];
+};
+static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
+constexpr int32_t kEmptyChild = (int32_t)0x80000000;
+
+// Triangle record, 48 B = 3 x dwordx4 (36 B of vertex data + ids riding in the .w lanes):
+//   q0 = (v0.xyz, bits(scene node id)), q1 = (v1.xyz, bits(triangle index inside its TriMesh)),
+//   q2 = (v2.xyz, 0).  Vertices are in mesh-local space and f32-EXACT (obj.rs:197-205 parses f32;
+//   loader3d.rs:669 divides by 4.0, which is exact), so widening to f64 reproduces the reference's
+//   f64 vertex exactly.
+struct TriRec {
+    float v0[3]; uint32_t node_id;
+    float v1[3]; uint32_t tri_id;
+    float v2[3]; uint32_t pad;
+};
+static_assert(sizeof(TriRec) == 48, "TriRec must be 48 bytes");
+
+// Per-triangle-corner texture coordinates (f32-exact, obj.rs parse_vt), fetched only at accepted hits.
+struct TriUv { float uv[6]; };
+
+enum InstanceFlags : uint32_t {
+    kInstSolid = 1u,         // SceneNode::solid (scene_node.rs:13)
+    kInstIdentityRot = 2u,   // rotation is exactly the identity: skip the ray transform
+    kInstAnyHit = 4u,        // shadow TLAS only: every node behind this BLAS is opaque (alpha == 1
+                             // for every hit), so the first hit within maxtoi blocks (scene.rs:328-330)
+    kInstHasUv = 8u          // the mesh(es) behind this BLAS carry uvs
+};
+
+// TLAS leaf payload: one analytic shape, or one BLAS (a single TriMesh node, or several TriMesh
+// nodes sharing one isometry merged into one BLAS — node ids then ride in TriRec::node_id).
+struct Instance {
+    double rot[9];   // R, local -> world, row-major (Isometry3::new, loader3d.rs:552)
+    double trans[3];
+    double params[3];
+    uint32_t kind;   // NraysShapeKind
+    uint32_t flags;  // InstanceFlags
+    int32_t node_id; // scene node, or -1 when the BLAS merges several nodes
+    int32_t blas_root; // root BvhNode index (TRIMESH) — or a leaf ref (< 0) for a 1-leaf BLAS
+};
+static_assert(sizeof(Instance) == 136, "Instance layout");
+
+// Shading record of a SceneNode (src/scene_node.rs:8-19).
+struct NodeRec {
+    float refl_mix, refl_atenuation, alpha;
+    uint32_t material_id;
+    double refr_coeff;
+    uint32_t pad[2];
+};
+static_assert(sizeof(NodeRec) == 32, "NodeRec layout");
+
+struct MaterialRec { // src/phong_material.rs:9-16
+    uint32_t kind;
+    float ka[3], kd[3], ks[3];
+    float shininess;
+    int32_t tex, alpha_tex;
+    uint32_t pad[3];
+};
+static_assert(sizeof(MaterialRec) == 64, "MaterialRec layout");
+
+struct TextureRec { // src/texture2d.rs:62-66
+    uint32_t width, height, format, interp, overflow, pad;
+    const void* texels;
+};
+
+struct LightRec { // src/light.rs:8-13
+    double pos[3];
+    double radius;
+    float color[3];
+    uint32_t racsample;
+};
+
+// Counters kept in HBM (one 64-bit atomic per wave per kernel for the ray classes; the traversal
+// counters are only touched by the instrumented kernel variants).
+struct DeviceCounters {
+    unsigned long long rays_reflection, rays_refraction, rays_shadow;
+    unsigned long long node_tests, tri_tests, prim_tests, hit_records, tex_samples;
+    unsigned int overflow; // set when a continuation queue ran out of capacity
+    unsigned int pad;
+};
+
+constexpr int kMaxGenerations = 64; // hard cap on trace depth (reference recursion is unbounded, scene.rs:246)
+
+// Continuation-ray queue (SoA in HBM): generation g reads queue[g & 1] with count[g] entries and
+// appends to queue[(g + 1) & 1] / count[g + 1] through wave ballot + prefix-sum compaction.
+struct RayQueue {
+    double* o[3];
+    double* d[3];
+    double* refr;            // RayWithEnergy::refr
+    float* energy;           // RayWithEnergy::energy
+    float* weight;           // product of blend factors from the primary ray down to this ray
+    uint32_t* pixel;         // index into the (tile-compact) output buffer
+    unsigned long long* key; // RNG path key
+};
+
+struct DScene {
+    const BvhNode* nodes;     // all BVH nodes (both TLASes and every BLAS)
+    const TriRec* tris;       // leaf-ordered triangles of every BLAS
+    const TriUv* triuvs;      // parallel to tris (may be null if no mesh has uvs)
+    const Instance* instances;        // closest-hit TLAS leaves (+ planes at the end)
+    const Instance* shadow_instances; // shadow TLAS leaves (+ planes at the end)
+    const NodeRec* node_recs;
+    const MaterialRec* materials;
+    const TextureRec* textures;
+    const LightRec* lights;
+    const int32_t* planes;        // indices into `instances` of planes (infinite AABB: tested linearly)
+    const int32_t* shadow_planes; // indices into `shadow_instances` of the same planes
+    int32_t closest_root;         // TLAS for Scene::trace (>= 0 node, < 0 leaf ref, kEmptyChild = empty)
+    int32_t shadow_root;          // TLAS for Scene::intersects_ray
+    uint32_t num_planes;
+    uint32_t num_lights;
+    float background[3];
+};
+
+struct DRender {
+    uint32_t width, height;      // full frame
+    uint32_t rows_local;         // rows in the compact (tile) buffer
+    uint32_t spp;                // ray_per_pixel
+    uint32_t sample_begin, sample_end; // samples handled by this launch
+    uint32_t max_depth;
+    uint32_t band_rows, band_owner, band_owners;
+    uint32_t first_batch;        // 1: store into out, 0: add
+    double window_width;
+    double eye[3];
+    double m[16];                // (P V)^-1 column-major
+    unsigned long long seed;
+};
+
+} // namespace nrays

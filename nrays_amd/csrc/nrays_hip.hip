@@ -1,0 +1,488 @@
+// nrays_hip.hip — gfx950 kernels and the C-ABI entry points of include/nrays_abi.h.
+//
+// Launch structure of one nrays_render (replaces scene::render, src/scene.rs:29-116):
+//   k_primary   one lane per pixel of a 16x16 tile (one 8x8 sub-tile per wave64), looping over the
+//               AA samples of the batch: raygen -> closest hit -> Phong + shadow rays -> pixel
+//               accumulation; reflection / refraction continuations are compacted with wave ballots
+//               into the generation-1 queue.  Persistent grid, XCD-aware tile order.
+//   k_bounce    generation g: grid-stride over the compacted queue, same per-ray work, atomicAdd of the
+//               weighted contribution into the pixel, continuations appended to generation g+1.
+//   k_resolve   divides by ray_per_pixel when it is > 1 (scene.rs:94).
+//   k_untile    un-permutes gathered multi-GPU tile buffers.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/nrays_abi.h"
+#include "device_types.h"
+#include "scene_build.h"
+#include "trace_device.h"
+
+namespace nrays {
+
+constexpr int kTile = 16;          // a workgroup renders a 16x16 pixel tile
+constexpr int kChunkTiles = 32;    // consecutive tiles given to one XCD before moving to the next
+constexpr int kMaxGrid = 2048;     // persistent grid: 256 CUs x 8 workgroups
+constexpr int kSpillDepth = 96;    // HBM spill entries per lane (only allocated for very deep trees)
+
+// Persistent-grid work index -> tile index.  Workgroup b is observed to run on XCD b % 8; chunks of
+// kChunkTiles consecutive tiles are dealt to XCDs round-robin so that each XCD's private L2 keeps
+// seeing the same region of the BVH while the image is still covered evenly (speed only — any
+// placement gives the same pixels).
+__device__ __forceinline__ uint32_t work_to_tile(uint32_t w) {
+    uint32_t xcd = w & 7u, j = w >> 3;
+    uint32_t chunk = j / kChunkTiles, within = j % kChunkTiles;
+    return (chunk * 8u + xcd) * kChunkTiles + within;
+}
+
+__device__ __forceinline__ void flush_counters(DeviceCounters* ctr, const Cnt& c, bool stats) {
+    // wave-level reduction, then one atomic per wave and class
+    unsigned sh = c.shadow, rl = c.refl, rf = c.refr;
+    unsigned nd = c.node, tr = c.tri, pr = c.prim, ht = c.hit, tx = c.tex;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        sh += __shfl_down(sh, off); rl += __shfl_down(rl, off); rf += __shfl_down(rf, off);
+        if (stats) { nd += __shfl_down(nd, off); tr += __shfl_down(tr, off); pr += __shfl_down(pr, off); ht += __shfl_down(ht, off); tx += __shfl_down(tx, off); }
+    }
+    if (__lane_id() == 0) {
+        if (sh) atomicAdd(&ctr->rays_shadow, (unsigned long long)sh);
+        if (rl) atomicAdd(&ctr->rays_reflection, (unsigned long long)rl);
+        if (rf) atomicAdd(&ctr->rays_refraction, (unsigned long long)rf);
+        if (stats) {
+            atomicAdd(&ctr->node_tests, (unsigned long long)nd); atomicAdd(&ctr->tri_tests, (unsigned long long)tr);
+            atomicAdd(&ctr->prim_tests, (unsigned long long)pr); atomicAdd(&ctr->hit_records, (unsigned long long)ht);
+            atomicAdd(&ctr->tex_samples, (unsigned long long)tx);
+        }
+    }
+}
+
+template <bool STATS>
+__global__ void __launch_bounds__(kBlock) k_primary(DScene S, DRender R, QueueOut qo, float* __restrict__ out, DeviceCounters* ctr,
+                                                     uint32_t* spill, uint32_t tiles_x, uint32_t tiles_y, uint32_t work_items) {
+    __shared__ uint32_t lds_stack[kLdsStack * kBlock];
+    Stack st;
+    st.lds = lds_stack + threadIdx.x;
+    st.spill_stride = gridDim.x * kBlock;
+    st.spill = spill ? spill + (size_t)blockIdx.x * kBlock + threadIdx.x : nullptr;
+    st.sp = 0;
+    Cnt cnt; cnt.node = cnt.tri = cnt.prim = cnt.hit = cnt.tex = cnt.shadow = cnt.refl = cnt.refr = 0;
+
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t lx = ((wave & 1u) << 3) | (lane & 7u), ly = ((wave >> 1) << 3) | (lane >> 3);
+    const uint32_t ntiles = tiles_x * tiles_y;
+
+    for (uint32_t w = blockIdx.x; w < work_items; w += gridDim.x) {
+        uint32_t tile = work_to_tile(w);
+        if (tile >= ntiles) continue; // block-uniform
+        uint32_t tx = tile % tiles_x, ty = tile / tiles_x;
+        uint32_t i = tx * kTile + lx, rl = ty * kTile + ly; // column, local (compact) row
+        // local row -> global row (framebuffer bands dealt round-robin to owners)
+        uint32_t j = rl;
+        if (R.band_rows != 0 && R.band_owners > 1) {
+            uint32_t lb = rl / R.band_rows;
+            j = (lb * R.band_owners + R.band_owner) * R.band_rows + (rl % R.band_rows);
+        }
+        bool active = i < R.width && rl < R.rows_local && j < R.height;
+        uint32_t pix = rl * R.width + i;
+        f3 tot = F3(0.0f, 0.0f, 0.0f);
+        for (uint32_t s = R.sample_begin; s < R.sample_end; ++s) {
+            RayState ray;
+            generate_primary(R, i, j, s, pix, ray);
+            f3 c = shade_and_continue<STATS>(S, st, active, ray, 0u, R.max_depth, qo, cnt);
+            tot.x = tot.x + c.x; tot.y = tot.y + c.y; tot.z = tot.z + c.z;
+        }
+        if (active) {
+            float* o = out + (size_t)pix * 3;
+            if (R.first_batch) { o[0] = tot.x; o[1] = tot.y; o[2] = tot.z; }
+            else { o[0] += tot.x; o[1] += tot.y; o[2] += tot.z; }
+        } else if (i < R.width && rl < R.rows_local && R.first_batch) { // padding rows of the last band
+            float* o = out + (size_t)pix * 3;
+            o[0] = 0.0f; o[1] = 0.0f; o[2] = 0.0f;
+        }
+    }
+    flush_counters(ctr, cnt, STATS);
+}
+
+template <bool STATS>
+__global__ void __launch_bounds__(kBlock) k_bounce(DScene S, RayQueue qin, const uint32_t* __restrict__ count_in, uint32_t capacity,
+                                                    QueueOut qo, float* __restrict__ out, DeviceCounters* ctr, uint32_t* spill,
+                                                    uint32_t depth, uint32_t max_depth) {
+    __shared__ uint32_t lds_stack[kLdsStack * kBlock];
+    Stack st;
+    st.lds = lds_stack + threadIdx.x;
+    st.spill_stride = gridDim.x * kBlock;
+    st.spill = spill ? spill + (size_t)blockIdx.x * kBlock + threadIdx.x : nullptr;
+    st.sp = 0;
+    Cnt cnt; cnt.node = cnt.tri = cnt.prim = cnt.hit = cnt.tex = cnt.shadow = cnt.refl = cnt.refr = 0;
+    uint32_t n = *count_in;
+    if (n > capacity) n = capacity;
+    for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) { // block-uniform trip count
+        uint32_t idx = base + threadIdx.x;
+        bool active = idx < n;
+        RayState ray;
+        ray.o = D3(0, 0, 0); ray.d = D3(0, 0, 1); ray.refr = 1.0; ray.energy = 0.0f; ray.weight = 0.0f; ray.key = 0; ray.pixel = 0;
+        if (active) queue_load(qin, idx, ray);
+        f3 c = shade_and_continue<STATS>(S, st, active, ray, depth, max_depth, qo, cnt);
+        if (active) {
+            float* o = out + (size_t)ray.pixel * 3;
+            unsafeAtomicAdd(o, c.x); unsafeAtomicAdd(o + 1, c.y); unsafeAtomicAdd(o + 2, c.z);
+        }
+    }
+    flush_counters(ctr, cnt, STATS);
+}
+
+__global__ void k_resolve(float* out, size_t n, float spp) { // pxs.push(tot_c / ray_per_pixel as f32), scene.rs:94
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = out[i] / spp;
+}
+
+__global__ void k_untile(const float* __restrict__ gathered, float* __restrict__ out, uint32_t width, uint32_t height,
+                         uint32_t band_rows, uint32_t owners, uint32_t rows_local) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t n = (size_t)width * height * 3;
+    if (idx >= n) return;
+    uint32_t c = (uint32_t)(idx % 3);
+    size_t p = idx / 3;
+    uint32_t i = (uint32_t)(p % width), j = (uint32_t)(p / width);
+    uint32_t band = j / band_rows, owner = band % owners, lb = band / owners;
+    uint32_t rl = lb * band_rows + (j % band_rows);
+    out[idx] = gathered[((size_t)owner * rows_local + rl) * width * 3 + (size_t)i * 3 + c];
+}
+
+// =============================================================================================
+// host side
+// =============================================================================================
+static thread_local std::string g_last_error;
+static int fail(int status, const std::string& msg) { g_last_error = msg; return status; }
+
+#define HIP_TRY(expr)                                                                                     \
+    do {                                                                                                  \
+        hipError_t e_ = (expr);                                                                           \
+        if (e_ != hipSuccess)                                                                             \
+            return fail(e_ == hipErrorOutOfMemory ? NRAYS_ERR_OOM : NRAYS_ERR_HIP,                        \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                               \
+    } while (0)
+
+struct QueueMem {
+    RayQueue q;
+    void* block = nullptr;
+};
+
+} // namespace nrays
+
+using namespace nrays;
+
+struct NraysScene {
+    int device = 0;
+    HostScene host;          // kept for counts only; bulk arrays are released after upload
+    DScene d;
+    std::vector<void*> allocs;
+    // per-scene transient state, grown on demand
+    QueueMem queue[2];
+    uint32_t queue_capacity = 0;
+    uint32_t* d_counts = nullptr;         // kMaxGenerations + 2 generation counters
+    DeviceCounters* d_counters = nullptr;
+    uint32_t* d_spill = nullptr;
+    bool need_spill = false;
+    float* d_frame = nullptr; size_t frame_floats = 0;
+    hipStream_t own_stream = nullptr;
+    hipEvent_t ev_begin = nullptr, ev_primary_end = nullptr, ev_end = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool have_last = false;
+    NraysStats last;
+    uint64_t last_primary = 0;
+    uint32_t last_generations = 0;
+    bool last_instrumented = false;
+};
+
+namespace nrays {
+
+template <typename T>
+static int upload(NraysScene* sc, const std::vector<T>& v, const T** out) {
+    *out = nullptr;
+    if (v.empty()) return NRAYS_OK;
+    void* p = nullptr;
+    HIP_TRY(hipMalloc(&p, v.size() * sizeof(T)));
+    sc->allocs.push_back(p);
+    HIP_TRY(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = (const T*)p;
+    return NRAYS_OK;
+}
+
+static int ensure_queue(NraysScene* sc, uint32_t capacity) {
+    if (capacity <= sc->queue_capacity) return NRAYS_OK;
+    for (int k = 0; k < 2; ++k) {
+        if (sc->queue[k].block) { (void)hipFree(sc->queue[k].block); sc->queue[k].block = nullptr; }
+        size_t cap = capacity;
+        size_t bytes = cap * (8 * 7 + 4 * 3 + 8);
+        void* p = nullptr;
+        HIP_TRY(hipMalloc(&p, bytes));
+        sc->queue[k].block = p;
+        char* c = (char*)p;
+        RayQueue& q = sc->queue[k].q;
+        for (int a = 0; a < 3; ++a) { q.o[a] = (double*)c; c += cap * 8; }
+        for (int a = 0; a < 3; ++a) { q.d[a] = (double*)c; c += cap * 8; }
+        q.refr = (double*)c; c += cap * 8;
+        q.key = (unsigned long long*)c; c += cap * 8;
+        q.energy = (float*)c; c += cap * 4;
+        q.weight = (float*)c; c += cap * 4;
+        q.pixel = (uint32_t*)c; c += cap * 4;
+    }
+    sc->queue_capacity = capacity;
+    return NRAYS_OK;
+}
+
+static uint32_t tile_rows(const NraysRenderParams* p) {
+    if (p->band_rows == 0 || p->band_owners <= 1) return p->height;
+    uint32_t nb = (p->height + p->band_rows - 1) / p->band_rows;
+    return ((nb + p->band_owners - 1) / p->band_owners) * p->band_rows;
+}
+
+static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out, hipStream_t stream, bool instrumented) {
+    if (!sc || !p || !d_out) return fail(NRAYS_ERR_BAD_ARG, "null argument");
+    if (p->ray_per_pixel == 0) return fail(NRAYS_ERR_BAD_ARG, "ray_per_pixel must be > 0 (scene.rs:37)");
+    if (p->width == 0 || p->height == 0) return fail(NRAYS_ERR_BAD_ARG, "empty resolution");
+    if (p->band_owners > 1 && (p->band_rows == 0 || p->band_owner >= p->band_owners)) return fail(NRAYS_ERR_BAD_ARG, "bad band parameters");
+    HIP_TRY(hipSetDevice(sc->device));
+
+    const uint32_t rows = tile_rows(p);
+    const uint64_t npix_local = (uint64_t)rows * p->width;
+    if (npix_local >= (1ull << 31)) return fail(NRAYS_ERR_UNSUPPORTED, "tile too large");
+
+    // sample batching keeps the number of primary rays (and hence continuation rays) per launch bounded
+    const uint64_t kMaxPrimaryPerLaunch = 32ull << 20;
+    uint32_t batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(p->ray_per_pixel, kMaxPrimaryPerLaunch / std::max<uint64_t>(1, npix_local)));
+
+    const bool continuations = sc->host.any_reflective || sc->host.any_transparent;
+    if (continuations) {
+        uint64_t want = std::min<uint64_t>(std::max<uint64_t>(4 * npix_local * batch, 1u << 16), 1ull << 27);
+        int rc = ensure_queue(sc, (uint32_t)want);
+        if (rc != NRAYS_OK) return rc;
+    }
+    if (sc->need_spill && !sc->d_spill) {
+        HIP_TRY(hipMalloc((void**)&sc->d_spill, (size_t)kMaxGrid * kBlock * kSpillDepth * sizeof(uint32_t)));
+    }
+
+    DRender R; std::memset(&R, 0, sizeof R);
+    R.width = p->width; R.height = p->height; R.rows_local = rows; R.spp = p->ray_per_pixel;
+    R.max_depth = p->max_depth;
+    R.band_rows = p->band_rows; R.band_owner = p->band_owner; R.band_owners = p->band_owners ? p->band_owners : 1;
+    R.window_width = p->window_width;
+    for (int a = 0; a < 3; ++a) R.eye[a] = p->camera_eye[a];
+    for (int a = 0; a < 16; ++a) R.m[a] = p->inv_proj_view[a];
+    R.seed = p->seed;
+
+    const uint32_t tiles_x = (p->width + kTile - 1) / kTile, tiles_y = (rows + kTile - 1) / kTile;
+    const uint32_t ntiles = tiles_x * tiles_y;
+    const uint32_t group = 8u * kChunkTiles;
+    const uint32_t work_items = ((ntiles + group - 1) / group) * group;
+    const uint32_t grid_primary = std::min<uint32_t>(work_items, kMaxGrid);
+
+    // generation budget: energy rule bound for reflection-only scenes, host-controlled otherwise
+    uint32_t gen_cap = kMaxGenerations;
+    if (p->max_depth != 0) gen_cap = std::min<uint32_t>(gen_cap, p->max_depth);
+    uint32_t gens_static = 0;
+    bool host_controlled = false;
+    if (continuations) {
+        if (sc->host.any_transparent) host_controlled = true;
+        else gens_static = std::min<uint32_t>(sc->host.reflection_generations, gen_cap);
+    }
+
+    HIP_TRY(hipMemsetAsync(sc->d_counters, 0, sizeof(DeviceCounters), stream));
+    HIP_TRY(hipEventRecord(sc->ev_begin, stream));
+    uint32_t generations_run = 0;
+    bool first_primary = true;
+    for (uint32_t s0 = 0; s0 < p->ray_per_pixel; s0 += batch) {
+        R.sample_begin = s0; R.sample_end = std::min<uint32_t>(p->ray_per_pixel, s0 + batch);
+        R.first_batch = s0 == 0 ? 1u : 0u;
+        if (continuations) HIP_TRY(hipMemsetAsync(sc->d_counts, 0, (kMaxGenerations + 2) * sizeof(uint32_t), stream));
+        QueueOut qo; qo.q = sc->queue[1].q; qo.capacity = continuations ? sc->queue_capacity : 0; qo.count = sc->d_counts + 1;
+        qo.overflow = &sc->d_counters->overflow;
+        if (instrumented) hipLaunchKernelGGL(k_primary<true>, dim3(grid_primary), dim3(kBlock), 0, stream, sc->d, R, qo, d_out, sc->d_counters, sc->d_spill, tiles_x, tiles_y, work_items);
+        else hipLaunchKernelGGL(k_primary<false>, dim3(grid_primary), dim3(kBlock), 0, stream, sc->d, R, qo, d_out, sc->d_counters, sc->d_spill, tiles_x, tiles_y, work_items);
+        HIP_TRY(hipGetLastError());
+        if (first_primary) { HIP_TRY(hipEventRecord(sc->ev_primary_end, stream)); first_primary = false; }
+
+        uint32_t gmax = host_controlled ? gen_cap : gens_static;
+        for (uint32_t g = 1; g <= gmax; ++g) {
+            uint32_t launch_n = sc->queue_capacity;
+            if (host_controlled) {
+                uint32_t n = 0;
+                HIP_TRY(hipMemcpyAsync(&n, sc->d_counts + g, sizeof n, hipMemcpyDeviceToHost, stream));
+                HIP_TRY(hipStreamSynchronize(stream));
+                if (n == 0) break;
+                launch_n = std::min<uint32_t>(n, sc->queue_capacity);
+            }
+            uint32_t grid = std::min<uint32_t>((launch_n + kBlock - 1) / kBlock, kMaxGrid);
+            QueueOut qn; qn.q = sc->queue[(g + 1) & 1].q; qn.capacity = sc->queue_capacity; qn.count = sc->d_counts + g + 1;
+            qn.overflow = &sc->d_counters->overflow;
+            if (instrumented) hipLaunchKernelGGL(k_bounce<true>, dim3(grid), dim3(kBlock), 0, stream, sc->d, sc->queue[g & 1].q, sc->d_counts + g, sc->queue_capacity, qn, d_out, sc->d_counters, sc->d_spill, g, p->max_depth);
+            else hipLaunchKernelGGL(k_bounce<false>, dim3(grid), dim3(kBlock), 0, stream, sc->d, sc->queue[g & 1].q, sc->d_counts + g, sc->queue_capacity, qn, d_out, sc->d_counters, sc->d_spill, g, p->max_depth);
+            HIP_TRY(hipGetLastError());
+            generations_run = std::max(generations_run, g);
+        }
+    }
+    if (p->ray_per_pixel > 1) {
+        size_t n = (size_t)npix_local * 3;
+        hipLaunchKernelGGL(k_resolve, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_out, n, (float)p->ray_per_pixel);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipEventRecord(sc->ev_end, stream));
+    sc->last_stream = stream; sc->have_last = true;
+    // owned rows only (padding rows of the last band carry no rays)
+    uint64_t owned_rows = 0;
+    if (p->band_rows == 0 || p->band_owners <= 1) owned_rows = p->height;
+    else for (uint32_t j = 0; j < p->height; ++j) if (((j / p->band_rows) % p->band_owners) == p->band_owner) ++owned_rows;
+    sc->last_primary = owned_rows * p->width * p->ray_per_pixel;
+    sc->last_generations = generations_run;
+    sc->last_instrumented = instrumented;
+    return NRAYS_OK;
+}
+
+} // namespace nrays
+
+extern "C" {
+
+uint32_t nrays_abi_version(void) { return NRAYS_ABI_VERSION; }
+const char* nrays_last_error(void) { return g_last_error.c_str(); }
+uint32_t nrays_tile_rows(const NraysRenderParams* params) { return params ? tile_rows(params) : 0; }
+
+int nrays_scene_create(const NraysSceneDesc* desc, NraysScene** out_scene) {
+    if (!desc || !out_scene) return fail(NRAYS_ERR_BAD_ARG, "null argument");
+    *out_scene = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(NRAYS_ERR_NO_DEVICE, "no HIP device visible");
+    NraysScene* sc = new (std::nothrow) NraysScene();
+    if (!sc) return fail(NRAYS_ERR_OOM, "host allocation failed");
+    auto bail = [&](int rc) { nrays_scene_destroy(sc); return rc; };
+    if (hipGetDevice(&sc->device) != hipSuccess) return bail(fail(NRAYS_ERR_HIP, "hipGetDevice failed"));
+    std::string err;
+    int rc = build_host_scene(desc, sc->host, err);
+    if (rc != NRAYS_OK) return bail(fail(rc, err));
+    HostScene& h = sc->host;
+    std::memset(&sc->d, 0, sizeof sc->d);
+    if ((rc = upload(sc, h.nodes, &sc->d.nodes)) != NRAYS_OK) return bail(rc);
+    if ((rc = upload(sc, h.tris, &sc->d.tris)) != NRAYS_OK) return bail(rc);
+    if ((rc = upload(sc, h.triuvs, &sc->d.triuvs)) != NRAYS_OK) return bail(rc);
+    if ((rc = upload(sc, h.instances, &sc->d.instances)) != NRAYS_OK) return bail(rc);
+    if ((rc = upload(sc, h.shadow_instances, &sc->d.shadow_instances)) != NRAYS_OK) return bail(rc);
+    if ((rc = upload(sc, h.node_recs, &sc->d.node_recs)) != NRAYS_OK) return bail(rc);
+    if ((rc = upload(sc, h.materials, &sc->d.materials)) != NRAYS_OK) return bail(rc);
+    if ((rc = upload(sc, h.lights, &sc->d.lights)) != NRAYS_OK) return bail(rc);
+    if ((rc = upload(sc, h.planes, &sc->d.planes)) != NRAYS_OK) return bail(rc);
+    if ((rc = upload(sc, h.shadow_planes, &sc->d.shadow_planes)) != NRAYS_OK) return bail(rc);
+    std::vector<TextureRec> trecs;
+    for (HostTexture& t : h.textures) {
+        void* p = nullptr;
+        if (hipMalloc(&p, t.bytes.size()) != hipSuccess) return bail(fail(NRAYS_ERR_OOM, "texture allocation failed"));
+        sc->allocs.push_back(p);
+        if (hipMemcpy(p, t.bytes.data(), t.bytes.size(), hipMemcpyHostToDevice) != hipSuccess) return bail(fail(NRAYS_ERR_HIP, "texture upload failed"));
+        TextureRec r = t.rec; r.texels = p; trecs.push_back(r);
+        std::vector<uint8_t>().swap(t.bytes);
+    }
+    if ((rc = upload(sc, trecs, &sc->d.textures)) != NRAYS_OK) return bail(rc);
+    sc->d.closest_root = h.closest_root; sc->d.shadow_root = h.shadow_root;
+    sc->d.num_planes = (uint32_t)h.planes.size(); sc->d.num_lights = (uint32_t)h.lights.size();
+    for (int a = 0; a < 3; ++a) sc->d.background[a] = h.background[a];
+    // stack bound: one deferred sibling per level of TLAS and BLAS, plus the sentinel
+    sc->need_spill = (2 * h.max_bvh_depth + 4) > kLdsStack;
+    // release bulk host copies
+    std::vector<BvhNode>().swap(h.nodes); std::vector<TriRec>().swap(h.tris); std::vector<TriUv>().swap(h.triuvs);
+
+    if (hipMalloc((void**)&sc->d_counts, (kMaxGenerations + 2) * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc((void**)&sc->d_counters, sizeof(DeviceCounters)) != hipSuccess)
+        return bail(fail(NRAYS_ERR_OOM, "counter allocation failed"));
+    if (hipMemset(sc->d_counts, 0, (kMaxGenerations + 2) * sizeof(uint32_t)) != hipSuccess ||
+        hipMemset(sc->d_counters, 0, sizeof(DeviceCounters)) != hipSuccess)
+        return bail(fail(NRAYS_ERR_HIP, "counter memset failed"));
+    if (hipStreamCreate(&sc->own_stream) != hipSuccess || hipEventCreate(&sc->ev_begin) != hipSuccess ||
+        hipEventCreate(&sc->ev_primary_end) != hipSuccess || hipEventCreate(&sc->ev_end) != hipSuccess)
+        return bail(fail(NRAYS_ERR_HIP, "stream/event creation failed"));
+    *out_scene = sc;
+    return NRAYS_OK;
+}
+
+void nrays_scene_destroy(NraysScene* sc) {
+    if (!sc) return;
+    (void)hipSetDevice(sc->device);
+    if (sc->have_last) (void)hipStreamSynchronize(sc->last_stream);
+    for (void* p : sc->allocs) (void)hipFree(p);
+    for (int k = 0; k < 2; ++k) if (sc->queue[k].block) (void)hipFree(sc->queue[k].block);
+    if (sc->d_counts) (void)hipFree(sc->d_counts);
+    if (sc->d_counters) (void)hipFree(sc->d_counters);
+    if (sc->d_spill) (void)hipFree(sc->d_spill);
+    if (sc->d_frame) (void)hipFree(sc->d_frame);
+    if (sc->ev_begin) (void)hipEventDestroy(sc->ev_begin);
+    if (sc->ev_primary_end) (void)hipEventDestroy(sc->ev_primary_end);
+    if (sc->ev_end) (void)hipEventDestroy(sc->ev_end);
+    if (sc->own_stream) (void)hipStreamDestroy(sc->own_stream);
+    delete sc;
+}
+
+int nrays_render_device(NraysScene* scene, const NraysRenderParams* params, float* out_rgb_device, void* hip_stream) {
+    return render_impl(scene, params, out_rgb_device, (hipStream_t)hip_stream, false);
+}
+
+int nrays_render_device_instrumented(NraysScene* scene, const NraysRenderParams* params, float* out_rgb_device, void* hip_stream) {
+    return render_impl(scene, params, out_rgb_device, (hipStream_t)hip_stream, true);
+}
+
+int nrays_get_stats(NraysScene* sc, NraysStats* out) {
+    if (!sc || !out) return fail(NRAYS_ERR_BAD_ARG, "null argument");
+    std::memset(out, 0, sizeof *out);
+    if (!sc->have_last) return NRAYS_OK;
+    HIP_TRY(hipSetDevice(sc->device));
+    HIP_TRY(hipStreamSynchronize(sc->last_stream));
+    DeviceCounters c;
+    HIP_TRY(hipMemcpy(&c, sc->d_counters, sizeof c, hipMemcpyDeviceToHost));
+    out->rays_primary = sc->last_primary;
+    out->rays_reflection = c.rays_reflection; out->rays_refraction = c.rays_refraction; out->rays_shadow = c.rays_shadow;
+    out->node_tests = c.node_tests; out->tri_tests = c.tri_tests; out->prim_tests = c.prim_tests;
+    out->hit_records = c.hit_records; out->tex_samples = c.tex_samples;
+    out->generations = sc->last_generations; out->instrumented = sc->last_instrumented ? 1u : 0u;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, sc->ev_begin, sc->ev_primary_end) == hipSuccess) out->kernel_ms_primary = ms;
+    if (hipEventElapsedTime(&ms, sc->ev_begin, sc->ev_end) == hipSuccess) out->kernel_ms_total = ms;
+    if (c.overflow) return fail(NRAYS_ERR_QUEUE_OVERFLOW, "continuation-ray queue overflow: image is incomplete");
+    return NRAYS_OK;
+}
+
+int nrays_render(NraysScene* sc, const NraysRenderParams* p, float* out_rgb) {
+    if (!sc || !p || !out_rgb) return fail(NRAYS_ERR_BAD_ARG, "null argument");
+    HIP_TRY(hipSetDevice(sc->device));
+    size_t floats = (size_t)tile_rows(p) * p->width * 3;
+    if (floats > sc->frame_floats) {
+        if (sc->d_frame) { (void)hipFree(sc->d_frame); sc->d_frame = nullptr; sc->frame_floats = 0; }
+        HIP_TRY(hipMalloc((void**)&sc->d_frame, floats * sizeof(float)));
+        sc->frame_floats = floats;
+    }
+    int rc = render_impl(sc, p, sc->d_frame, sc->own_stream, false);
+    if (rc != NRAYS_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(out_rgb, sc->d_frame, floats * sizeof(float), hipMemcpyDeviceToHost, sc->own_stream));
+    HIP_TRY(hipStreamSynchronize(sc->own_stream));
+    unsigned int overflow = 0;
+    HIP_TRY(hipMemcpy(&overflow, &sc->d_counters->overflow, sizeof overflow, hipMemcpyDeviceToHost));
+    if (overflow) return fail(NRAYS_ERR_QUEUE_OVERFLOW, "continuation-ray queue overflow: image is incomplete");
+    return NRAYS_OK;
+}
+
+int nrays_untile_device(const float* gathered, float* out_rgb_device, uint32_t width, uint32_t height, uint32_t band_rows,
+                        uint32_t band_owners, void* hip_stream) {
+    if (!gathered || !out_rgb_device || width == 0 || height == 0 || band_rows == 0 || band_owners == 0)
+        return fail(NRAYS_ERR_BAD_ARG, "bad untile arguments");
+    NraysRenderParams p; std::memset(&p, 0, sizeof p);
+    p.width = width; p.height = height; p.band_rows = band_rows; p.band_owners = band_owners;
+    uint32_t rows_local = band_owners > 1 ? tile_rows(&p) : height;
+    size_t n = (size_t)width * height * 3;
+    hipLaunchKernelGGL(k_untile, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, gathered, out_rgb_device,
+                       width, height, band_rows, band_owners, rows_local);
+    HIP_TRY(hipGetLastError());
+    return NRAYS_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,275 @@
+// scene_build.cpp — NraysSceneDesc -> HostScene (see scene_build.h).
+#include "scene_build.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <map>
+
+#include "bvh_build.h"
+
+namespace nrays {
+namespace {
+
+// Isometry3::new(translation, axis_angle) -> rotation matrix, via the unit quaternion
+// (cos(a/2), axis*sin(a/2)) like nalgebra's UnitQuaternion::from_scaled_axis (loader3d.rs:552).
+void rotation_from_axis_angle(const double w[3], double R[9], bool& identity) {
+    double angle = std::sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+    if (angle == 0.0) {
+        for (int i = 0; i < 9; ++i) R[i] = (i % 4 == 0) ? 1.0 : 0.0;
+        identity = true;
+        return;
+    }
+    identity = false;
+    double s = std::sin(angle / 2.0), qw = std::cos(angle / 2.0);
+    double qi = w[0] / angle * s, qj = w[1] / angle * s, qk = w[2] / angle * s;
+    double ww = qw * qw, ii = qi * qi, jj = qj * qj, kk = qk * qk;
+    double ij = qi * qj * 2.0, wk = qw * qk * 2.0, wj = qw * qj * 2.0, ik = qi * qk * 2.0, jk = qj * qk * 2.0, wi = qw * qi * 2.0;
+    R[0] = ww + ii - jj - kk; R[1] = ij - wk;           R[2] = wj + ik;
+    R[3] = wk + ij;           R[4] = ww - ii + jj - kk; R[5] = jk - wi;
+    R[6] = ik - wj;           R[7] = wi + jk;           R[8] = ww - ii - jj + kk;
+}
+
+// Conservative f32 world box of a local box [c - h, c + h] under (R, t).
+PrimBounds world_box(const double R[9], const double t[3], const double c[3], const double h[3]) {
+    PrimBounds b;
+    for (int i = 0; i < 3; ++i) {
+        double wc = R[3 * i] * c[0] + R[3 * i + 1] * c[1] + R[3 * i + 2] * c[2] + t[i];
+        double wh = std::fabs(R[3 * i]) * h[0] + std::fabs(R[3 * i + 1]) * h[1] + std::fabs(R[3 * i + 2]) * h[2];
+        // outward f32 rounding plus one more ulp to absorb the f64 rounding of the transform itself
+        b.mn[i] = std::nextafterf(round_down_f32(wc - wh), -std::numeric_limits<float>::infinity());
+        b.mx[i] = std::nextafterf(round_up_f32(wc + wh), std::numeric_limits<float>::infinity());
+    }
+    return b;
+}
+
+bool shape_has_uv(uint32_t kind) { return kind == NRAYS_SHAPE_BALL || kind == NRAYS_SHAPE_CUBOID; }
+
+struct Blas {
+    int32_t root;
+    float mn[3], mx[3]; // local bounds
+};
+
+// Appends a BLAS over the triangles of `node_ids` (TriMesh nodes sharing one isometry).
+int append_blas(const NraysSceneDesc* d, const std::vector<uint32_t>& node_ids, HostScene& out, Blas& blas, std::string& err) {
+    std::vector<PrimBounds> pb;
+    std::vector<TriRec> recs;
+    std::vector<TriUv> uvs;
+    for (uint32_t ni : node_ids) {
+        const NraysMesh& m = d->meshes[d->nodes[ni].mesh_id];
+        for (uint32_t t = 0; t < m.num_triangles; ++t) {
+            TriRec r; TriUv uv; PrimBounds b;
+            std::memset(&uv, 0, sizeof uv);
+            float* vs[3] = {r.v0, r.v1, r.v2};
+            for (int a = 0; a < 3; ++a) { b.mn[a] = std::numeric_limits<float>::infinity(); b.mx[a] = -std::numeric_limits<float>::infinity(); }
+            for (int k = 0; k < 3; ++k) {
+                uint32_t vi = m.indices[3 * t + k];
+                if (vi >= m.num_vertices) { err = "triangle index out of range"; return NRAYS_ERR_BAD_ARG; }
+                for (int a = 0; a < 3; ++a) {
+                    double x = m.vertices[3 * (size_t)vi + a];
+                    float f = (float)x;
+                    if (!((double)f == x)) { // also rejects NaN
+                        err = "mesh vertex coordinate is not exactly representable in f32 (see DESIGN.md: f32-exact mesh storage)";
+                        return NRAYS_ERR_UNSUPPORTED;
+                    }
+                    vs[k][a] = f;
+                    b.mn[a] = std::min(b.mn[a], f); b.mx[a] = std::max(b.mx[a], f);
+                }
+                if (m.uvs) {
+                    for (int a = 0; a < 2; ++a) {
+                        double x = m.uvs[2 * (size_t)vi + a];
+                        float f = (float)x;
+                        if (!((double)f == x)) { err = "mesh uv is not exactly representable in f32"; return NRAYS_ERR_UNSUPPORTED; }
+                        uv.uv[2 * k + a] = f;
+                    }
+                }
+            }
+            r.node_id = ni; r.tri_id = t; r.pad = 0;
+            recs.push_back(r); uvs.push_back(uv); pb.push_back(b);
+        }
+    }
+    for (int a = 0; a < 3; ++a) { blas.mn[a] = std::numeric_limits<float>::infinity(); blas.mx[a] = -std::numeric_limits<float>::infinity(); }
+    for (const PrimBounds& b : pb) for (int a = 0; a < 3; ++a) { blas.mn[a] = std::min(blas.mn[a], b.mn[a]); blas.mx[a] = std::max(blas.mx[a], b.mx[a]); }
+    BuiltBvh bvh = build_bvh(pb, 4);
+    if (out.tris.size() + recs.size() >= (1u << 28)) { err = "too many triangles"; return NRAYS_ERR_UNSUPPORTED; }
+    rebase_bvh(bvh, (int32_t)out.nodes.size(), (uint32_t)out.tris.size());
+    out.max_bvh_depth = std::max(out.max_bvh_depth, bvh.max_depth);
+    for (uint32_t k : bvh.order) { out.tris.push_back(recs[k]); out.triuvs.push_back(uvs[k]); }
+    out.nodes.insert(out.nodes.end(), bvh.nodes.begin(), bvh.nodes.end());
+    blas.root = bvh.root;
+    return NRAYS_OK;
+}
+
+// Builds a TLAS over `insts` (reordering them in place) and appends its nodes.
+int32_t append_tlas(std::vector<Instance>& insts, const std::vector<PrimBounds>& boxes, HostScene& out) {
+    BuiltBvh bvh = build_bvh(boxes, 1);
+    std::vector<Instance> re(insts.size());
+    for (size_t k = 0; k < bvh.order.size(); ++k) re[k] = insts[bvh.order[k]];
+    insts.swap(re);
+    rebase_bvh(bvh, (int32_t)out.nodes.size(), 0);
+    out.max_bvh_depth = std::max(out.max_bvh_depth, bvh.max_depth);
+    out.nodes.insert(out.nodes.end(), bvh.nodes.begin(), bvh.nodes.end());
+    return bvh.root;
+}
+
+} // namespace
+
+int build_host_scene(const NraysSceneDesc* d, HostScene& out, std::string& err) {
+    if (!d) { err = "null scene descriptor"; return NRAYS_ERR_BAD_ARG; }
+    if ((d->num_lights && !d->lights) || (d->num_materials && !d->materials) || (d->num_textures && !d->textures) ||
+        (d->num_meshes && !d->meshes) || (d->num_nodes && !d->nodes)) { err = "null array with non-zero count"; return NRAYS_ERR_BAD_ARG; }
+    for (int a = 0; a < 3; ++a) out.background[a] = d->background[a];
+
+    for (uint32_t i = 0; i < d->num_lights; ++i) {
+        const NraysLight& l = d->lights[i];
+        LightRec r;
+        for (int a = 0; a < 3; ++a) { r.pos[a] = l.pos[a]; r.color[a] = l.color[a]; }
+        r.radius = l.radius; r.racsample = l.racsample;
+        out.lights.push_back(r);
+    }
+    for (uint32_t i = 0; i < d->num_textures; ++i) {
+        const NraysTexture& t = d->textures[i];
+        if (t.width < 1 || t.height < 1 || !t.texels || t.format > NRAYS_TEXEL_RGBA32F) { err = "bad texture"; return NRAYS_ERR_BAD_ARG; }
+        HostTexture h;
+        h.rec.width = t.width; h.rec.height = t.height; h.rec.format = t.format; h.rec.interp = t.interp;
+        h.rec.overflow = t.overflow; h.rec.pad = 0; h.rec.texels = nullptr;
+        size_t nbytes = (size_t)t.width * t.height * (t.format == NRAYS_TEXEL_RGBA8 ? 4 : 16);
+        h.bytes.assign((const uint8_t*)t.texels, (const uint8_t*)t.texels + nbytes);
+        out.textures.push_back(std::move(h));
+    }
+    for (uint32_t i = 0; i < d->num_materials; ++i) {
+        const NraysMaterial& m = d->materials[i];
+        if (m.kind > NRAYS_MAT_UV) { err = "bad material kind"; return NRAYS_ERR_BAD_ARG; }
+        if (m.texture_id >= (int32_t)d->num_textures || m.alpha_texture_id >= (int32_t)d->num_textures) { err = "bad texture id"; return NRAYS_ERR_BAD_ARG; }
+        MaterialRec r; std::memset(&r, 0, sizeof r);
+        r.kind = m.kind;
+        for (int a = 0; a < 3; ++a) { r.ka[a] = m.ambiant[a]; r.kd[a] = m.diffuse[a]; r.ks[a] = m.specular[a]; }
+        r.shininess = m.shininess;
+        r.tex = m.texture_id < 0 ? -1 : m.texture_id;
+        r.alpha_tex = m.alpha_texture_id < 0 ? -1 : m.alpha_texture_id;
+        out.materials.push_back(r);
+    }
+
+    // ---- per-node records, opacity classification, transform groups ----------------------
+    struct NodeInfo { double R[9]; bool identity; bool opaque; bool has_uv; };
+    std::vector<NodeInfo> info(d->num_nodes);
+    float att_min = std::numeric_limits<float>::infinity();
+    for (uint32_t i = 0; i < d->num_nodes; ++i) {
+        const NraysNode& n = d->nodes[i];
+        if (n.shape_kind > NRAYS_SHAPE_TRIMESH) { err = "bad shape kind"; return NRAYS_ERR_BAD_ARG; }
+        if (n.material_id >= d->num_materials) { err = "bad material id"; return NRAYS_ERR_BAD_ARG; }
+        if (n.shape_kind == NRAYS_SHAPE_TRIMESH && (n.mesh_id < 0 || (uint32_t)n.mesh_id >= d->num_meshes)) { err = "bad mesh id"; return NRAYS_ERR_BAD_ARG; }
+        rotation_from_axis_angle(n.axis_angle, info[i].R, info[i].identity);
+        const NraysMaterial& m = d->materials[n.material_id];
+        bool has_uv = n.shape_kind == NRAYS_SHAPE_TRIMESH ? d->meshes[n.mesh_id].uvs != nullptr : shape_has_uv(n.shape_kind);
+        info[i].has_uv = has_uv;
+        // ambiant().w is 1 for NormalMaterial, 1/0 for UVMaterial with/without uvs, and the alpha
+        // map's w (or 1) for PhongMaterial; a node blocks shadow rays iff w * node.alpha >= 1 (scene.rs:322-331).
+        bool w_is_one = m.kind == NRAYS_MAT_NORMAL || (m.kind == NRAYS_MAT_UV && has_uv) ||
+                        (m.kind == NRAYS_MAT_PHONG && (m.alpha_texture_id < 0 || !has_uv));
+        info[i].opaque = w_is_one && n.alpha >= 1.0f;
+        if (!(w_is_one && n.alpha == 1.0f)) out.any_transparent = true;
+        if (n.refl_mix != 0.0f) { out.any_reflective = true; att_min = std::min(att_min, n.refl_atenuation); }
+        NodeRec r;
+        r.refl_mix = n.refl_mix; r.refl_atenuation = n.refl_atenuation; r.alpha = n.alpha; r.material_id = n.material_id;
+        r.refr_coeff = n.refr_coeff; r.pad[0] = has_uv ? 1u : 0u; r.pad[1] = 0;
+        out.node_recs.push_back(r);
+    }
+    if (out.any_reflective) {
+        uint32_t k = 0; float e = 1.0f;
+        if (!(att_min > 0.0f)) k = kMaxGenerations;
+        else while (e > 0.1f && k < (uint32_t)kMaxGenerations) { ++k; e = e - att_min; }
+        out.reflection_generations = k;
+    }
+
+    std::vector<Instance> cinst, sinst, planes_c, planes_s;
+    std::vector<PrimBounds> cbox, sbox;
+
+    auto base_instance = [&](uint32_t ni) {
+        const NraysNode& n = d->nodes[ni];
+        Instance in; std::memset(&in, 0, sizeof in);
+        for (int k = 0; k < 9; ++k) in.rot[k] = info[ni].R[k];
+        for (int k = 0; k < 3; ++k) { in.trans[k] = n.translation[k]; in.params[k] = n.params[k]; }
+        in.kind = n.shape_kind;
+        in.flags = (n.solid ? kInstSolid : 0u) | (info[ni].identity ? kInstIdentityRot : 0u) | (info[ni].has_uv ? kInstHasUv : 0u);
+        in.node_id = (int32_t)ni; in.blas_root = kEmptyChild;
+        return in;
+    };
+
+    // analytic shapes
+    for (uint32_t i = 0; i < d->num_nodes; ++i) {
+        const NraysNode& n = d->nodes[i];
+        if (n.shape_kind == NRAYS_SHAPE_TRIMESH) continue;
+        Instance in = base_instance(i);
+        Instance si = in;
+        if (info[i].opaque) si.flags |= kInstAnyHit;
+        if (n.shape_kind == NRAYS_SHAPE_PLANE) { planes_c.push_back(in); planes_s.push_back(si); continue; }
+        double c[3] = {0, 0, 0}, h[3];
+        double Rid[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        const double* R = info[i].R;
+        switch (n.shape_kind) {
+        case NRAYS_SHAPE_BALL: h[0] = h[1] = h[2] = n.params[0]; R = Rid; break; // rotation ignored (SURVEY B-4)
+        case NRAYS_SHAPE_CUBOID: h[0] = n.params[0]; h[1] = n.params[1]; h[2] = n.params[2]; break;
+        case NRAYS_SHAPE_CAPSULE: h[0] = h[2] = n.params[1]; h[1] = n.params[0] + n.params[1]; break;
+        default: h[0] = h[2] = n.params[1]; h[1] = n.params[0]; break; // cylinder, cone
+        }
+        for (int a = 0; a < 3; ++a) h[a] = std::fabs(h[a]);
+        PrimBounds b = world_box(R, n.translation, c, h);
+        cinst.push_back(in); cbox.push_back(b);
+        sinst.push_back(si); sbox.push_back(b);
+    }
+
+    // TriMesh nodes grouped by identical isometry
+    std::map<std::vector<uint64_t>, std::vector<uint32_t>> groups;
+    std::vector<std::vector<uint64_t>> group_order;
+    for (uint32_t i = 0; i < d->num_nodes; ++i) {
+        const NraysNode& n = d->nodes[i];
+        if (n.shape_kind != NRAYS_SHAPE_TRIMESH) continue;
+        if (d->meshes[n.mesh_id].num_triangles == 0) continue;
+        std::vector<uint64_t> key(6);
+        std::memcpy(&key[0], n.translation, 24); std::memcpy(&key[3], n.axis_angle, 24);
+        if (!groups.count(key)) group_order.push_back(key);
+        groups[key].push_back(i);
+    }
+    for (const auto& key : group_order) {
+        const std::vector<uint32_t>& ids = groups[key];
+        uint32_t n0 = ids[0];
+        auto add = [&](const std::vector<uint32_t>& sub, bool closest, bool shadow, bool anyhit, const Blas* reuse, Blas& blas) -> int {
+            if (!reuse) { int rc = append_blas(d, sub, out, blas, err); if (rc != NRAYS_OK) return rc; } else blas = *reuse;
+            Instance in = base_instance(n0);
+            in.flags &= ~(uint32_t)kInstSolid; // TriMesh ignores `solid` (SURVEY B-8)
+            in.node_id = sub.size() == 1 ? (int32_t)sub[0] : -1;
+            in.blas_root = blas.root;
+            double c[3], h[3];
+            for (int a = 0; a < 3; ++a) { c[a] = 0.5 * ((double)blas.mn[a] + (double)blas.mx[a]); h[a] = 0.5 * ((double)blas.mx[a] - (double)blas.mn[a]); }
+            PrimBounds b = world_box(info[n0].R, d->nodes[n0].translation, c, h);
+            if (closest) { cinst.push_back(in); cbox.push_back(b); }
+            if (shadow) { Instance si = in; if (anyhit) si.flags |= kInstAnyHit; sinst.push_back(si); sbox.push_back(b); }
+            return NRAYS_OK;
+        };
+        std::vector<uint32_t> opaque, transp;
+        for (uint32_t i : ids) (info[i].opaque ? opaque : transp).push_back(i);
+        Blas all; int rc;
+        if (transp.empty()) {
+            rc = add(ids, true, true, true, nullptr, all); if (rc != NRAYS_OK) return rc;
+        } else {
+            rc = add(ids, true, false, false, nullptr, all); if (rc != NRAYS_OK) return rc;
+            Blas tmp;
+            if (!opaque.empty()) { rc = add(opaque, false, true, true, nullptr, tmp); if (rc != NRAYS_OK) return rc; }
+            for (uint32_t i : transp) { rc = add(std::vector<uint32_t>{i}, false, true, false, nullptr, tmp); if (rc != NRAYS_OK) return rc; }
+        }
+    }
+
+    out.closest_root = append_tlas(cinst, cbox, out);
+    out.shadow_root = append_tlas(sinst, sbox, out);
+    for (size_t k = 0; k < planes_c.size(); ++k) {
+        out.planes.push_back((int32_t)cinst.size()); cinst.push_back(planes_c[k]);
+        out.shadow_planes.push_back((int32_t)sinst.size()); sinst.push_back(planes_s[k]);
+    }
+    out.instances.swap(cinst);
+    out.shadow_instances.swap(sinst);
+    return NRAYS_OK;
+}
+
+} // namespace nrays

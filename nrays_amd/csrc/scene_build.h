@@ -1,0 +1,40 @@
+// scene_build.h — flattens an NraysSceneDesc (the data Scene::new / SceneNode::new receive,
+// src/scene.rs:119, src/scene_node.rs:22) into the HBM layout of device_types.h.  Host only.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "../../include/nrays_abi.h"
+#include "device_types.h"
+
+namespace nrays {
+
+struct HostTexture {
+    TextureRec rec;               // texels pointer filled at upload
+    std::vector<uint8_t> bytes;   // copy of the texel data
+};
+
+struct HostScene {
+    std::vector<BvhNode> nodes;
+    std::vector<TriRec> tris;
+    std::vector<TriUv> triuvs;
+    std::vector<Instance> instances;         // closest TLAS order, planes appended at the end
+    std::vector<Instance> shadow_instances;  // shadow TLAS order, planes appended at the end
+    std::vector<int32_t> planes, shadow_planes;
+    std::vector<NodeRec> node_recs;
+    std::vector<MaterialRec> materials;
+    std::vector<HostTexture> textures;
+    std::vector<LightRec> lights;
+    int32_t closest_root = kEmptyChild, shadow_root = kEmptyChild;
+    float background[3] = {1.f, 1.f, 1.f};
+    // generation control (see nrays_hip.hip)
+    bool any_reflective = false;   // some node has refl_mix != 0 (scene.rs:204)
+    bool any_transparent = false;  // some node can produce alpha != 1 (scene.rs:229)
+    uint32_t reflection_generations = 0; // upper bound from the energy rule (scene.rs:204-206)
+    int max_bvh_depth = 0;
+};
+
+// Returns NRAYS_OK or a negative NraysStatus with `err` set.
+int build_host_scene(const NraysSceneDesc* desc, HostScene& out, std::string& err);
+
+} // namespace nrays

@@ -1,0 +1,856 @@
+// trace_device.h — gfx950 device code of the nrays trace loop: ray/shape intersectors, two-level
+// BVH traversal with an LDS-resident stack, Phong shading with shadow rays, continuation-ray
+// emission through wave ballot + prefix-sum compaction.
+//
+// Reference functions replaced:
+//   a1  render pixel/AA loop               src/scene.rs:67-95          -> generate_primary()
+//   a4  ClosestRayTOICostFn + best_first   src/scene.rs:262-283        -> traverse<false>()
+//   a5  SceneNode::cast + ncollide shapes  src/scene_node.rs:51-54     -> cast_*()
+//   a6  ray/triangle                       ncollide (SURVEY B-8)       -> cast_triangle()
+//   a7  TransparentShadowsRayTOICostFn     src/scene.rs:147-161,285-339-> traverse<true>()
+//   a8-a10 Scene::trace / reflection / refraction  src/scene.rs:163-252-> shade_and_continue()
+//   a11 PhongMaterial                      src/phong_material.rs:39-151-> material_*()
+//   a12 Light::sample                      src/light.rs:57-63          -> light loop in material_compute()
+//   a13 Texture2d::sample                  src/texture2d.rs:203-256    -> tex_sample()
+//   a14 Normal/UV materials                src/{normal,uv}_material.rs -> material_ambiant()
+//
+// Numerics: geometry in f64 (Scalar = f64, src/lib.rs:33), colour in f32, the same operation order
+// as the reference / ncollide; the translation unit is compiled with -ffp-contract=off so that no
+// a*b+c is fused (Rust never fuses), which keeps hit/miss decisions bit-identical to a strict IEEE
+// evaluation.  BVH bounds are f32 rounded outward and tested with a relative slack, so box culling is
+// a strict superset of the reference's and never changes a result.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "device_types.h"
+
+namespace nrays {
+
+constexpr int kBlock = 256;     // threads per workgroup = 4 wave64
+constexpr int kLdsStack = 32;   // traversal-stack entries kept in LDS per lane (then spills to HBM)
+constexpr int32_t kSentinel = (int32_t)0x80000001; // marks "leave the BLAS" on the traversal stack
+
+#define NR_DEV __device__ __forceinline__
+
+// ---------------------------------------------------------------- vector algebra (f64) -------
+struct d3 { double x, y, z; };
+NR_DEV d3 D3(double x, double y, double z) { d3 r; r.x = x; r.y = y; r.z = z; return r; }
+NR_DEV d3 operator+(d3 a, d3 b) { return D3(a.x + b.x, a.y + b.y, a.z + b.z); }
+NR_DEV d3 operator-(d3 a, d3 b) { return D3(a.x - b.x, a.y - b.y, a.z - b.z); }
+NR_DEV d3 operator*(d3 a, double s) { return D3(a.x * s, a.y * s, a.z * s); }
+NR_DEV d3 operator/(d3 a, double s) { return D3(a.x / s, a.y / s, a.z / s); }
+NR_DEV d3 operator-(d3 a) { return D3(-a.x, -a.y, -a.z); }
+NR_DEV double dot(d3 a, d3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+NR_DEV d3 cross(d3 a, d3 b) { return D3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+NR_DEV double norm(d3 a) { return sqrt(dot(a, a)); }
+NR_DEV d3 normalize(d3 a) { return a / norm(a); }
+NR_DEV double comp(d3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+
+struct f3 { float x, y, z; };
+NR_DEV f3 F3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+struct f4 { float x, y, z, w; };
+
+// ---------------------------------------------------------------- RNG -------
+NR_DEV unsigned long long rng_mix(unsigned long long z) {
+    z ^= z >> 30; z *= 0xbf58476d1ce4e5b9ULL;
+    z ^= z >> 27; z *= 0x94d049bb133111ebULL;
+    z ^= z >> 31;
+    return z;
+}
+NR_DEV unsigned long long rng_hash(unsigned long long key, unsigned long long salt) {
+    return rng_mix((key ^ (salt * 0x9E3779B97F4A7C15ULL)) + 0xD1B54A32D192ED03ULL);
+}
+NR_DEV double rng_u01(unsigned long long key, unsigned long long dim) {
+    return (double)(rng_hash(key, 0x1000ULL + dim) >> 11) * (1.0 / 9007199254740992.0);
+}
+constexpr unsigned long long kSaltPath = 2ULL, kSaltRefl = 0x100ULL, kSaltRefr = 0x101ULL, kSaltLight = 0x200ULL;
+
+// ---------------------------------------------------------------- counters -------------------
+struct Cnt {
+    unsigned node, tri, prim, hit, tex;     // instrumented builds only
+    unsigned shadow, refl, refr;            // ray classes, always counted
+};
+
+// ---------------------------------------------------------------- traversal stack ------------
+// Entries 0..kLdsStack-1 live in LDS, laid out [entry][lane] so a wave's access is conflict-free
+// (stride-1 dwords across lanes); deeper entries spill to a per-lane column in HBM.
+struct Stack {
+    uint32_t* lds;   // &lds_stack[threadIdx.x]
+    uint32_t* spill; // &spill[global lane]   (may be null when the tree depth fits in LDS)
+    uint32_t spill_stride;
+    int sp;
+    NR_DEV void push(int32_t v) {
+        if (sp < kLdsStack) lds[sp * kBlock] = (uint32_t)v;
+        else spill[(size_t)(sp - kLdsStack) * spill_stride] = (uint32_t)v;
+        ++sp;
+    }
+    NR_DEV int32_t pop() {
+        --sp;
+        if (sp < kLdsStack) return (int32_t)lds[sp * kBlock];
+        return (int32_t)spill[(size_t)(sp - kLdsStack) * spill_stride];
+    }
+};
+
+// ---------------------------------------------------------------- intersection record --------
+struct Isect {
+    double toi;
+    d3 n;
+    double u, v;
+    bool has_uv;
+};
+
+struct Xform { // Isometry3: R (row-major) and translation
+    double r[9];
+    d3 t;
+};
+NR_DEV d3 rot(const Xform& m, d3 v) {
+    return D3(m.r[0] * v.x + m.r[1] * v.y + m.r[2] * v.z, m.r[3] * v.x + m.r[4] * v.y + m.r[5] * v.z, m.r[6] * v.x + m.r[7] * v.y + m.r[8] * v.z);
+}
+NR_DEV d3 inv_rot(const Xform& m, d3 v) {
+    return D3(m.r[0] * v.x + m.r[3] * v.y + m.r[6] * v.z, m.r[1] * v.x + m.r[4] * v.y + m.r[7] * v.z, m.r[2] * v.x + m.r[5] * v.y + m.r[8] * v.z);
+}
+
+constexpr double kPi = 3.14159265358979323846;
+constexpr double kDblMax = 1.7976931348623157e308;
+
+// ncollide Ball (SURVEY B-4): centre = translation, rotation ignored.
+NR_DEV bool cast_ball(double radius, d3 center, d3 o, d3 d, bool solid, Isect& out) {
+    d3 dc = o - center;
+    double a = dot(d, d), b = dot(dc, d), c = dot(dc, dc) - radius * radius;
+    if (c > 0.0 && b > 0.0) return false;
+    double delta = b * b - a * c;
+    if (delta < 0.0) return false;
+    double sq = sqrt(delta);
+    double t = (-b - sq) / a;
+    bool inside = false;
+    if (t <= 0.0) { inside = true; t = solid ? 0.0 : (-b + sq) / a; }
+    d3 pos = (o + d * t) - center;
+    d3 n = normalize(pos);
+    out.toi = t;
+    out.has_uv = true;
+    out.u = 0.5 + atan2(n.z, n.x) / (kPi * 2.0);
+    out.v = 0.5 - asin(n.y) / kPi;
+    out.n = inside ? -n : n;
+    return true;
+}
+
+// ncollide Cuboid via ray_aabb on [-he, he] (SURVEY B-5).
+NR_DEV bool cast_cuboid(d3 he, const Xform& m, d3 o, d3 d, bool solid, Isect& out) {
+    d3 lo = inv_rot(m, o - m.t), ld = inv_rot(m, d);
+    double tmax = kDblMax, tmin = -kDblMax;
+    int near_side = 0, far_side = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        double dd = comp(ld, i), oo = comp(lo, i), mx = comp(he, i), mn = -mx;
+        if (dd == 0.0) {
+            if (oo < mn || oo > mx) return false;
+        } else {
+            double denom = 1.0 / dd;
+            double tn = (mn - oo) * denom, tf = (mx - oo) * denom;
+            bool flip = false;
+            if (tn > tf) { double s = tn; tn = tf; tf = s; flip = true; }
+            if (tn > tmin) { tmin = tn; near_side = flip ? -(i + 1) : (i + 1); }
+            if (tf < tmax) { tmax = tf; far_side = flip ? (i + 1) : -(i + 1); }
+            if (tmax < 0.0 || tmin > tmax) return false;
+        }
+    }
+    d3 n = D3(0.0, 0.0, 0.0);
+    double t; int side;
+    if (tmin < 0.0) {
+        side = far_side;
+        if (solid) t = 0.0;
+        else {
+            t = tmax;
+            double s = far_side < 0 ? -1.0 : 1.0;
+            int ax = (far_side < 0 ? -far_side : far_side) - 1;
+            if (far_side != 0) { if (ax == 0) n.x = s; else if (ax == 1) n.y = s; else n.z = s; }
+        }
+    } else {
+        t = tmin; side = near_side;
+        double s = near_side < 0 ? 1.0 : -1.0;
+        int ax = (near_side < 0 ? -near_side : near_side) - 1;
+        if (near_side != 0) { if (ax == 0) n.x = s; else if (ax == 1) n.y = s; else n.z = s; }
+    }
+    d3 pt = lo + ld * t;
+    d3 dpt = pt - (-he);
+    d3 scale = he - (-he);
+    int id = side < 0 ? -side : side;
+    out.toi = t; out.n = rot(m, n); out.has_uv = true;
+    if (id == 1) { out.u = dpt.y / scale.y; out.v = dpt.z / scale.z; }
+    else if (id == 2) { out.u = dpt.z / scale.z; out.v = dpt.x / scale.x; }
+    else { out.u = dpt.x / scale.x; out.v = dpt.y / scale.y; }
+    return true;
+}
+
+// ncollide Plane (SURVEY B-6).
+NR_DEV bool cast_plane(d3 pn, const Xform& m, d3 o, d3 d, bool solid, Isect& out) {
+    d3 lo = inv_rot(m, o - m.t), ld = inv_rot(m, d);
+    double dot_normal_dpos = dot(pn, -lo);
+    out.has_uv = false; out.u = 0.0; out.v = 0.0;
+    if (solid && dot_normal_dpos > 0.0) { out.toi = 0.0; out.n = D3(0.0, 0.0, 0.0); return true; }
+    double denom = dot(pn, ld);
+    if (denom == 0.0) return false;
+    double t = dot_normal_dpos / denom;
+    if (t >= 0.0) {
+        d3 n = dot_normal_dpos > 0.0 ? -pn : pn;
+        out.toi = t; out.n = rot(m, n);
+        return true;
+    }
+    return false;
+}
+
+// Shared tail of the closed-form convex casts (cylinder / cone / capsule).
+NR_DEV bool convex_interval_hit(double t0, double t1, d3 n0, d3 n1, d3 ld, const Xform& m, bool solid, Isect& out) {
+    if (!(t0 <= t1) || t1 < 0.0) return false;
+    out.has_uv = false; out.u = 0.0; out.v = 0.0;
+    if (t0 > 0.0) { out.toi = t0; out.n = rot(m, n0); return true; }
+    if (solid) { out.toi = 0.0; out.n = rot(m, -ld); return true; }
+    out.toi = t1; out.n = rot(m, n1);
+    return true;
+}
+
+NR_DEV bool cast_cylinder(double hh, double r, const Xform& m, d3 o, d3 d, bool solid, Isect& out) {
+    d3 lo = inv_rot(m, o - m.t), ld = inv_rot(m, d);
+    double t0 = -kDblMax, t1 = kDblMax;
+    bool enter_side = true, exit_side = true;
+    double A = ld.x * ld.x + ld.z * ld.z;
+    double B = lo.x * ld.x + lo.z * ld.z;
+    double C = lo.x * lo.x + lo.z * lo.z - r * r;
+    if (A == 0.0) { if (C > 0.0) return false; }
+    else {
+        double disc = B * B - A * C;
+        if (disc < 0.0) return false;
+        double sq = sqrt(disc);
+        t0 = (-B - sq) / A; t1 = (-B + sq) / A;
+    }
+    if (ld.y == 0.0) { if (lo.y < -hh || lo.y > hh) return false; }
+    else {
+        double ta = (-hh - lo.y) / ld.y, tb = (hh - lo.y) / ld.y;
+        if (ta > tb) { double s = ta; ta = tb; tb = s; }
+        if (ta > t0) { t0 = ta; enter_side = false; }
+        if (tb < t1) { t1 = tb; exit_side = false; }
+    }
+    if (!(t0 <= t1) || t1 < 0.0) return false;
+    d3 n0, n1;
+    if (enter_side) { d3 p = lo + ld * t0; double s = sqrt(p.x * p.x + p.z * p.z); n0 = D3(p.x / s, 0.0, p.z / s); }
+    else n0 = D3(0.0, ld.y > 0.0 ? -1.0 : 1.0, 0.0);
+    if (exit_side) { d3 p = lo + ld * t1; double s = sqrt(p.x * p.x + p.z * p.z); n1 = D3(p.x / s, 0.0, p.z / s); }
+    else n1 = D3(0.0, ld.y > 0.0 ? 1.0 : -1.0, 0.0);
+    return convex_interval_hit(t0, t1, n0, n1, ld, m, solid, out);
+}
+
+NR_DEV d3 cone_side_normal(d3 p, double hh, double k2) {
+    d3 g = D3(p.x, k2 * (hh - p.y), p.z);
+    double s = norm(g);
+    if (s == 0.0) return D3(0.0, 1.0, 0.0);
+    return g / s;
+}
+NR_DEV bool cast_cone(double hh, double r, const Xform& m, d3 o, d3 d, bool solid, Isect& out) {
+    d3 lo = inv_rot(m, o - m.t), ld = inv_rot(m, d);
+    double k = r / (2.0 * hh), k2 = k * k;
+    double ow = hh - lo.y, dw = -ld.y;
+    double s0 = -kDblMax, s1 = kDblMax;
+    int s0_kind = 0, s1_kind = 0;
+    if (dw == 0.0) { if (ow < 0.0 || ow > 2.0 * hh) return false; }
+    else {
+        double ta = (0.0 - ow) / dw, tb = (2.0 * hh - ow) / dw;
+        if (ta <= tb) { s0 = ta; s0_kind = 1; s1 = tb; s1_kind = 2; }
+        else { s0 = tb; s0_kind = 2; s1 = ta; s1_kind = 1; }
+    }
+    double A = ld.x * ld.x + ld.z * ld.z - k2 * dw * dw;
+    double B = lo.x * ld.x + lo.z * ld.z - k2 * ow * dw;
+    double C = lo.x * lo.x + lo.z * lo.z - k2 * ow * ow;
+    double t0 = s0, t1 = s1;
+    int k0 = s0_kind, k1 = s1_kind;
+    if (A > 0.0) {
+        double disc = B * B - A * C;
+        if (disc < 0.0) return false;
+        double sq = sqrt(disc);
+        double ra = (-B - sq) / A, rb = (-B + sq) / A;
+        if (ra > t0) { t0 = ra; k0 = 0; }
+        if (rb < t1) { t1 = rb; k1 = 0; }
+    } else if (A < 0.0) {
+        double disc = B * B - A * C;
+        if (disc > 0.0) {
+            double sq = sqrt(disc);
+            double lo_r = (-B + sq) / A, hi_r = (-B - sq) / A;
+            double a1 = hi_r > s0 ? hi_r : s0;
+            double b0 = lo_r < s1 ? lo_r : s1;
+            if (a1 <= s1) { if (hi_r > s0) { t0 = hi_r; k0 = 0; } }
+            else if (s0 <= b0) { if (lo_r < s1) { t1 = lo_r; k1 = 0; } }
+            else return false;
+        }
+    } else {
+        if (B == 0.0) { if (C > 0.0) return false; }
+        else {
+            double ts = -C / (2.0 * B);
+            if (B > 0.0) { if (ts < t1) { t1 = ts; k1 = 0; } }
+            else { if (ts > t0) { t0 = ts; k0 = 0; } }
+        }
+    }
+    if (!(t0 <= t1) || t1 < 0.0) return false;
+    d3 n0, n1;
+    if (k0 == 0) n0 = cone_side_normal(lo + ld * t0, hh, k2); else n0 = D3(0.0, k0 == 1 ? 1.0 : -1.0, 0.0);
+    if (k1 == 0) n1 = cone_side_normal(lo + ld * t1, hh, k2); else n1 = D3(0.0, k1 == 1 ? 1.0 : -1.0, 0.0);
+    return convex_interval_hit(t0, t1, n0, n1, ld, m, solid, out);
+}
+
+NR_DEV bool cast_capsule(double hh, double r, const Xform& m, d3 o, d3 d, bool solid, Isect& out) {
+    d3 lo = inv_rot(m, o - m.t), ld = inv_rot(m, d);
+    double t0 = kDblMax, t1 = -kDblMax;
+    d3 n0 = D3(0.0, 0.0, 0.0), n1 = D3(0.0, 0.0, 0.0);
+    {
+        double a0 = -kDblMax, a1 = kDblMax; bool ok = true;
+        double A = ld.x * ld.x + ld.z * ld.z;
+        double B = lo.x * ld.x + lo.z * ld.z;
+        double C = lo.x * lo.x + lo.z * lo.z - r * r;
+        if (A == 0.0) { if (C > 0.0) ok = false; }
+        else {
+            double disc = B * B - A * C;
+            if (disc < 0.0) ok = false;
+            else { double sq = sqrt(disc); a0 = (-B - sq) / A; a1 = (-B + sq) / A; }
+        }
+        bool e_side = true, x_side = true;
+        if (ok) {
+            if (ld.y == 0.0) { if (lo.y < -hh || lo.y > hh) ok = false; }
+            else {
+                double ta = (-hh - lo.y) / ld.y, tb = (hh - lo.y) / ld.y;
+                if (ta > tb) { double s = ta; ta = tb; tb = s; }
+                if (ta > a0) { a0 = ta; e_side = false; }
+                if (tb < a1) { a1 = tb; x_side = false; }
+            }
+        }
+        if (ok && a0 <= a1) {
+            t0 = a0; t1 = a1;
+            if (e_side) { d3 p = lo + ld * a0; n0 = D3(p.x / r, 0.0, p.z / r); }
+            if (x_side) { d3 p = lo + ld * a1; n1 = D3(p.x / r, 0.0, p.z / r); }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        d3 c = D3(0.0, s == 0 ? -hh : hh, 0.0);
+        d3 dc = lo - c;
+        double a = dot(ld, ld), b = dot(dc, ld), cc = dot(dc, dc) - r * r;
+        double delta = b * b - a * cc;
+        if (delta < 0.0) continue;
+        double sq = sqrt(delta);
+        double b0 = (-b - sq) / a, b1 = (-b + sq) / a;
+        if (b0 < t0) { t0 = b0; n0 = ((lo + ld * b0) - c) / r; }
+        if (b1 > t1) { t1 = b1; n1 = ((lo + ld * b1) - c) / r; }
+    }
+    return convex_interval_hit(t0, t1, n0, n1, ld, m, solid, out);
+}
+
+// ncollide triangle_ray_intersection (SURVEY B-8).  `full` also produces the normal and barycentrics.
+NR_DEV bool cast_triangle(d3 a, d3 b, d3 c, d3 o, d3 d, double& toi, d3* normal, double* bary) {
+    d3 ab = b - a, ac = c - a;
+    d3 n = cross(ab, ac);
+    double dn = dot(n, d);
+    if (dn == 0.0) return false;
+    d3 ap = o - a;
+    double t = dot(ap, n);
+    if ((t < 0.0 && dn < 0.0) || (t > 0.0 && dn > 0.0)) return false;
+    double dabs = fabs(dn);
+    d3 e = -cross(d, ap);
+    double v, w, invd;
+    if (t < 0.0) {
+        v = -dot(ac, e);
+        if (v < 0.0 || v > dabs) return false;
+        w = dot(ab, e);
+        if (w < 0.0 || v + w > dabs) return false;
+        invd = 1.0 / dabs;
+        toi = -t * invd;
+        if (normal) *normal = -normalize(n);
+    } else {
+        v = dot(ac, e);
+        if (v < 0.0 || v > dabs) return false;
+        w = -dot(ab, e);
+        if (w < 0.0 || v + w > dabs) return false;
+        invd = 1.0 / dabs;
+        toi = t * invd;
+        if (normal) *normal = normalize(n);
+    }
+    if (bary) { v = v * invd; w = w * invd; bary[0] = -v - w + 1.0; bary[1] = v; bary[2] = w; }
+    return true;
+}
+
+NR_DEV void load_xform(const Instance& in, Xform& m) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) m.r[k] = in.rot[k];
+    m.t = D3(in.trans[0], in.trans[1], in.trans[2]);
+}
+
+// SceneNode::cast for the analytic shapes (scene_node.rs:51-54).
+__device__ __noinline__ bool cast_analytic(const Instance& in, d3 o, d3 d, Isect& out) {
+    bool solid = (in.flags & kInstSolid) != 0;
+    Xform m; load_xform(in, m);
+    switch (in.kind) {
+    case NRAYS_SHAPE_BALL: return cast_ball(in.params[0], m.t, o, d, solid, out);
+    case NRAYS_SHAPE_CUBOID: return cast_cuboid(D3(in.params[0], in.params[1], in.params[2]), m, o, d, solid, out);
+    case NRAYS_SHAPE_CYLINDER: return cast_cylinder(in.params[0], in.params[1], m, o, d, solid, out);
+    case NRAYS_SHAPE_CAPSULE: return cast_capsule(in.params[0], in.params[1], m, o, d, solid, out);
+    case NRAYS_SHAPE_CONE: return cast_cone(in.params[0], in.params[1], m, o, d, solid, out);
+    case NRAYS_SHAPE_PLANE: return cast_plane(D3(in.params[0], in.params[1], in.params[2]), m, o, d, solid, out);
+    default: return false;
+    }
+}
+
+// ---------------------------------------------------------------- textures & materials -------
+NR_DEV f4 tex_at(const TextureRec& t, uint32_t x, uint32_t y) {
+    size_t i = (size_t)y * t.width + x;
+    f4 r;
+    if (t.format == NRAYS_TEXEL_RGBA8) {
+        uchar4 p = ((const uchar4*)t.texels)[i];
+        r.x = (float)p.x / 255.0f; r.y = (float)p.y / 255.0f; r.z = (float)p.z / 255.0f; r.w = (float)p.w / 255.0f;
+    } else {
+        float4 p = ((const float4*)t.texels)[i];
+        r.x = p.x; r.y = p.y; r.z = p.z; r.w = p.w;
+    }
+    return r;
+}
+// Texture2d::sample (texture2d.rs:207-256), taps clamped to the last row/column.
+template <bool STATS>
+NR_DEV f4 tex_sample(const TextureRec& t, double u, double v, Cnt& cnt) {
+    if (STATS) cnt.tex++;
+    float ux = (float)u, uy = (float)v;
+    if (t.overflow == NRAYS_OVERFLOW_CLAMP) {
+        ux = ux < 0.0f ? 0.0f : (ux > 1.0f ? 1.0f : ux);
+        uy = uy < 0.0f ? 0.0f : (uy > 1.0f ? 1.0f : uy);
+    } else {
+        ux = fmodf(ux, 1.0f); uy = fmodf(uy, 1.0f);
+        if (ux < 0.0f) ux = 1.0f + ux;
+        if (uy < 0.0f) uy = 1.0f + uy;
+    }
+    ux = ux * (float)(t.width - 1);
+    uy = uy * (float)(t.height - 1);
+    uint32_t wm = t.width - 1, hm = t.height - 1;
+    if (t.interp == NRAYS_INTERP_NEAREST) {
+        uint32_t x = (uint32_t)roundf(ux), y = (uint32_t)roundf(uy);
+        if (x > wm) x = wm;
+        if (y > hm) y = hm;
+        return tex_at(t, x, y);
+    }
+    uint32_t lx = (uint32_t)floorf(ux), ly = (uint32_t)floorf(uy);
+    if (lx > wm) lx = wm;
+    if (ly > hm) ly = hm;
+    uint32_t hx = lx + 1, hy = ly + 1;
+    float sx = ux - (float)lx, sy = uy - (float)ly;
+    if (hx > wm) hx = wm;
+    if (hy > hm) hy = hm;
+    f4 ul = tex_at(t, lx, hy), ur = tex_at(t, hx, hy), dr = tex_at(t, hx, ly), dl = tex_at(t, lx, ly);
+    f4 ui, di, r;
+    ui.x = ul.x * (1.0f - sx) + ur.x * sx; ui.y = ul.y * (1.0f - sx) + ur.y * sx; ui.z = ul.z * (1.0f - sx) + ur.z * sx; ui.w = ul.w * (1.0f - sx) + ur.w * sx;
+    di.x = dl.x * (1.0f - sx) + dr.x * sx; di.y = dl.y * (1.0f - sx) + dr.y * sx; di.z = dl.z * (1.0f - sx) + dr.z * sx; di.w = dl.w * (1.0f - sx) + dr.w * sx;
+    r.x = ui.x * sy + di.x * (1.0f - sy); r.y = ui.y * sy + di.y * (1.0f - sy); r.z = ui.z * sy + di.z * (1.0f - sy); r.w = ui.w * sy + di.w * (1.0f - sy);
+    return r;
+}
+
+// Material::ambiant (phong_material.rs:39-70, normal_material.rs:9-14, uv_material.rs:10-20).
+template <bool STATS>
+NR_DEV f4 material_ambiant(const DScene& S, const MaterialRec& m, const Isect& in, Cnt& cnt) {
+    f4 r;
+    if (m.kind == NRAYS_MAT_NORMAL) {
+        r.x = (1.0f + (float)in.n.x) / 2.0f; r.y = (1.0f + (float)in.n.y) / 2.0f; r.z = (1.0f + (float)in.n.z) / 2.0f; r.w = 1.0f;
+        return r;
+    }
+    if (m.kind == NRAYS_MAT_UV) {
+        if (in.has_uv) { r.x = (float)in.u; r.y = (float)in.v; r.z = 0.0f; r.w = 1.0f; }
+        else { r.x = r.y = r.z = r.w = 0.0f; }
+        return r;
+    }
+    if (in.has_uv) {
+        f4 tc; tc.x = tc.y = tc.z = tc.w = 1.0f;
+        if (m.tex >= 0) { tc = tex_sample<STATS>(S.textures[m.tex], in.u, in.v, cnt); tc.w = 1.0f; }
+        if (m.alpha_tex >= 0) tc.w = tex_sample<STATS>(S.textures[m.alpha_tex], in.u, in.v, cnt).w;
+        r.x = m.ka[0] * tc.x; r.y = m.ka[1] * tc.y; r.z = m.ka[2] * tc.z; r.w = 1.0f * tc.w;
+    } else { r.x = m.ka[0]; r.y = m.ka[1]; r.z = m.ka[2]; r.w = 1.0f; }
+    return r;
+}
+
+// ---------------------------------------------------------------- BVH traversal --------------
+struct Hit {
+    double t;
+    uint32_t inst; // index into the TLAS's instance array
+    uint32_t prim; // global triangle slot (TRIMESH) else 0
+};
+
+// f32 view of a ray for box culling.  The BVH bounds are exact f32 supersets of the f64 geometry; the
+// slab test runs in f32 with explicit error margins so that it is a SUPERSET of the f64 slab test
+// (ncollide ray_aabb, called at src/scene.rs:276) and can therefore never change a result:
+//   o32 = fl(o)            |o - o32| <= |o| 2^-24          -> absolute margin e = |o32 * inv32| 2^-22 per axis
+//   inv32 = fl(1/d)        relative error <= 2^-24 (+2^-53)
+//   t = fl(fl(b - o32) * inv32)  relative error <= 3 * 2^-24 -> relative slack 2^-21 on the final compare
+// A zero direction component uses the finite inverse 1e30 (no NaN from 0 * inf; the margin then
+// decides inside/outside of the slab conservatively).
+struct RayF {
+    float ox, oy, oz, ix, iy, iz, ex, ey, ez;
+};
+NR_DEV float inv_f32(double d) {
+    float r = d == 0.0 ? 1e30f : (float)(1.0 / d);
+    if (!(fabsf(r) < 1e30f)) r = copysignf(1e30f, r);
+    return r;
+}
+NR_DEV RayF make_rayf(d3 o, d3 d) {
+    RayF r;
+    r.ox = (float)o.x; r.oy = (float)o.y; r.oz = (float)o.z;
+    r.ix = inv_f32(d.x); r.iy = inv_f32(d.y); r.iz = inv_f32(d.z);
+    r.ex = fabsf(r.ox * r.ix) * 2.384185791015625e-07f; // 2^-22
+    r.ey = fabsf(r.oy * r.iy) * 2.384185791015625e-07f;
+    r.ez = fabsf(r.oz * r.iz) * 2.384185791015625e-07f;
+    return r;
+}
+// Upper f32 bound of the current best distance (ties with it must still be visited).
+NR_DEV float best_f32(double bt) { return (float)bt * 1.0000004f + 1e-37f; }
+
+// Returns the (approximate) entry distance, or -1 on a miss.
+NR_DEV float box_entry(float mnx, float mny, float mnz, float mxx, float mxy, float mxz, const RayF& r, float tbest) {
+    float x1 = (mnx - r.ox) * r.ix, x2 = (mxx - r.ox) * r.ix;
+    float y1 = (mny - r.oy) * r.iy, y2 = (mxy - r.oy) * r.iy;
+    float z1 = (mnz - r.oz) * r.iz, z2 = (mxz - r.oz) * r.iz;
+    float xn = fminf(x1, x2) - r.ex, xf = fmaxf(x1, x2) + r.ex;
+    float yn = fminf(y1, y2) - r.ey, yf = fmaxf(y1, y2) + r.ey;
+    float zn = fminf(z1, z2) - r.ez, zf = fmaxf(z1, z2) + r.ez;
+    float tn = fmaxf(fmaxf(xn, yn), fmaxf(zn, 0.0f));
+    float tf = fminf(fminf(xf, yf), fminf(zf, tbest));
+    return (tn * 0.9999995f <= tf * 1.0000005f) ? tn : -1.0f;
+}
+
+// Reconstructs the full intersection record of a finished closest-hit query.
+template <bool SHADOW>
+NR_DEV void resolve_hit(const DScene& S, d3 o, d3 d, const Hit& h, Isect& out, uint32_t& node_id) {
+    const Instance& in = (SHADOW ? S.shadow_instances : S.instances)[h.inst];
+    if (in.kind != NRAYS_SHAPE_TRIMESH) {
+        cast_analytic(in, o, d, out);
+        node_id = (uint32_t)in.node_id;
+        return;
+    }
+    Xform m; load_xform(in, m);
+    d3 lo = o, ld = d;
+    if (!(in.flags & kInstIdentityRot)) { lo = inv_rot(m, o - m.t); ld = inv_rot(m, d); }
+    else lo = o - m.t;
+    const TriRec& tr = S.tris[h.prim];
+    d3 a = D3(tr.v0[0], tr.v0[1], tr.v0[2]), b = D3(tr.v1[0], tr.v1[1], tr.v1[2]), c = D3(tr.v2[0], tr.v2[1], tr.v2[2]);
+    double bary[3]; d3 n; double toi;
+    cast_triangle(a, b, c, lo, ld, toi, &n, bary);
+    out.toi = toi;
+    out.n = (in.flags & kInstIdentityRot) ? n : rot(m, n);
+    node_id = tr.node_id;
+    out.has_uv = (S.node_recs[node_id].pad[0] & 1u) != 0;
+    out.u = 0.0; out.v = 0.0;
+    if (out.has_uv) {
+        const TriUv& uv = S.triuvs[h.prim];
+        out.u = (double)uv.uv[0] * bary[0] + (double)uv.uv[2] * bary[1] + (double)uv.uv[4] * bary[2];
+        out.v = (double)uv.uv[1] * bary[0] + (double)uv.uv[3] * bary[1] + (double)uv.uv[5] * bary[2];
+    }
+}
+
+// Shadow-ray bookkeeping of one node-closest hit (scene.rs:313-338): returns true if it blocks.
+template <bool STATS>
+NR_DEV bool shadow_node_hit(const DScene& S, uint32_t node_id, const Isect& is, f3& filter, Cnt& cnt) {
+    if (STATS) cnt.hit++;
+    const NodeRec& nr = S.node_recs[node_id];
+    f4 color = material_ambiant<STATS>(S, S.materials[nr.material_id], is, cnt);
+    float alpha = color.w * nr.alpha;
+    if (alpha < 1.0f) {
+        filter.x = (filter.x * color.x) * (1.0f - alpha);
+        filter.y = (filter.y * color.y) * (1.0f - alpha);
+        filter.z = (filter.z * color.z) * (1.0f - alpha);
+        return false;
+    }
+    return true;
+}
+
+// Two-level traversal.
+//   SHADOW == false: ClosestRayTOICostFn — global closest hit (ties: smallest node id, then
+//                    smallest triangle id); returns true and `hit` if anything was hit.
+//   SHADOW == true : TransparentShadowsRayTOICostFn — returns true if an opaque node-closest hit
+//                    lies within `tlimit`; otherwise `filter` holds the product of the transparent
+//                    node-closest hits' colour filters.
+template <bool SHADOW, bool STATS>
+NR_DEV bool traverse(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, Hit& hit, f3& filter, Cnt& cnt) {
+    const Instance* insts = SHADOW ? S.shadow_instances : S.instances;
+    double bt = SHADOW ? tlimit : kDblMax;
+    unsigned long long bkey = ~0ULL;
+    bool bhit = false;
+    uint32_t binst = 0, bprim = 0;
+    // current (possibly instance-local) ray
+    d3 co = o, cd = d;
+    RayF rf = make_rayf(o, d);
+    float btf = best_f32(bt);
+    bool in_blas = false;
+    uint32_t cur_inst = 0, cur_flags = 0;
+    st.sp = 0;
+    // planes have infinite AABBs (ncollide Plane AABB = +-MAX): kept out of the BVH and visited as
+    // pseudo-leaves, pushed first so that they are tested after the TLAS has tightened the bound.
+    {
+        const int32_t* planes = SHADOW ? S.shadow_planes : S.planes;
+        for (uint32_t p = 0; p < S.num_planes; ++p) st.push(~(int32_t)(((uint32_t)planes[p]) << 3));
+    }
+    int32_t cur = SHADOW ? S.shadow_root : S.closest_root;
+
+    for (;;) {
+        if (cur == kEmptyChild) {
+            if (st.sp == 0) break;
+            cur = st.pop();
+            if (cur == kSentinel) { // the BLAS of `cur_inst` is exhausted: back to world space
+                in_blas = false;
+                co = o; cd = d; rf = make_rayf(o, d);
+                if (SHADOW && !(cur_flags & kInstAnyHit)) {
+                    if (bhit) {
+                        Hit h; h.t = bt; h.inst = cur_inst; h.prim = bprim;
+                        Isect is; uint32_t node_id;
+                        resolve_hit<true>(S, o, d, h, is, node_id);
+                        if (shadow_node_hit<STATS>(S, node_id, is, filter, cnt)) return true;
+                    }
+                    bt = tlimit; bkey = ~0ULL; bhit = false; btf = best_f32(bt);
+                }
+                cur = kEmptyChild;
+            }
+            continue;
+        }
+        if (cur >= 0) { // internal node: one 64-byte fetch, two box tests
+            const float4* q = (const float4*)(S.nodes + cur);
+            float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+            int32_t left = __float_as_int(q3.x), right = __float_as_int(q3.y);
+            if (STATS) cnt.node += 2;
+            float tl = box_entry(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, rf, btf);
+            float tr = box_entry(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, rf, btf);
+            bool hl = tl >= 0.0f && left != kEmptyChild, hr = tr >= 0.0f && right != kEmptyChild;
+            if (hl && hr) {
+                if (tr < tl) { st.push(left); cur = right; }
+                else { st.push(right); cur = left; }
+            } else cur = hl ? left : (hr ? right : kEmptyChild);
+            continue;
+        }
+        // leaf
+        uint32_t lv = (uint32_t)~cur;
+        uint32_t first = lv >> 3, count = (lv & 7u) + 1u;
+        if (!in_blas) { // TLAS leaf = one instance
+            const Instance& in = insts[first];
+            if (in.kind == NRAYS_SHAPE_TRIMESH) {
+                cur_inst = first; cur_flags = in.flags;
+                Xform m; load_xform(in, m);
+                if (in.flags & kInstIdentityRot) { co = o - m.t; cd = d; }
+                else { co = inv_rot(m, o - m.t); cd = inv_rot(m, d); }
+                rf = make_rayf(co, cd);
+                in_blas = true;
+                st.push(kSentinel);
+                cur = in.blas_root;
+                continue;
+            }
+            if (STATS) cnt.prim++;
+            Isect is;
+            if (cast_analytic(in, o, d, is)) {
+                if (SHADOW) {
+                    if (is.toi <= tlimit && shadow_node_hit<STATS>(S, (uint32_t)in.node_id, is, filter, cnt)) return true;
+                } else {
+                    unsigned long long key = (unsigned long long)(uint32_t)in.node_id << 32;
+                    if (is.toi < bt || (is.toi == bt && key < bkey)) { bt = is.toi; bkey = key; bhit = true; binst = first; bprim = 0; btf = best_f32(bt); }
+                }
+            }
+            cur = kEmptyChild;
+            continue;
+        }
+        // triangle leaf
+        for (uint32_t k = 0; k < count; ++k) {
+            const float4* tq = (const float4*)(S.tris + first + k);
+            float4 t0 = tq[0], t1 = tq[1], t2 = tq[2];
+            if (STATS) cnt.tri++;
+            double toi;
+            if (cast_triangle(D3(t0.x, t0.y, t0.z), D3(t1.x, t1.y, t1.z), D3(t2.x, t2.y, t2.z), co, cd, toi, nullptr, nullptr)) {
+                if (SHADOW && (cur_flags & kInstAnyHit)) { if (toi <= tlimit) return true; }
+                else {
+                    unsigned long long key = SHADOW ? (unsigned long long)__float_as_uint(t1.w)
+                                                    : (((unsigned long long)__float_as_uint(t0.w) << 32) | __float_as_uint(t1.w));
+                    if (toi < bt || (toi == bt && key < bkey)) { bt = toi; bkey = key; bhit = true; binst = cur_inst; bprim = first + k; btf = best_f32(bt); }
+                }
+            }
+        }
+        cur = kEmptyChild;
+    }
+
+    if (SHADOW) return false;
+    hit.t = bt; hit.inst = binst; hit.prim = bprim;
+    return bhit;
+}
+
+// ---------------------------------------------------------------- shading --------------------
+struct RayState { // RayWithEnergy (ray_with_energy.rs:4-8) + bookkeeping of the iterative formulation
+    d3 o, d;
+    double refr;
+    float energy;
+    float weight;
+    unsigned long long key;
+    uint32_t pixel;
+};
+
+// PhongMaterial::compute (phong_material.rs:72-151); other materials fall back to ambiant (material.rs:8-16).
+template <bool STATS>
+NR_DEV f4 material_compute(const DScene& S, Stack& st, const MaterialRec& m, const RayState& ray, d3 point, const Isect& in, Cnt& cnt) {
+    if (m.kind != NRAYS_MAT_PHONG) return material_ambiant<STATS>(S, m, in, cnt);
+    f4 tex; tex.x = tex.y = tex.z = tex.w = 1.0f;
+    float alpha = 1.0f;
+    if (in.has_uv && m.tex >= 0) tex = tex_sample<STATS>(S.textures[m.tex], in.u, in.v, cnt);
+    if (in.has_uv && m.alpha_tex >= 0) alpha = tex_sample<STATS>(S.textures[m.alpha_tex], in.u, in.v, cnt).w;
+    f3 res = F3(m.ka[0] * tex.x, m.ka[1] * tex.y, m.ka[2] * tex.z);
+    d3 normal = in.n;
+    for (uint32_t li = 0; li < S.num_lights; ++li) {
+        const LightRec& light = S.lights[li];
+        f3 acc = F3(0.0f, 0.0f, 0.0f);
+        uint32_t ns = light.racsample * light.racsample;
+        unsigned long long lkey = rng_hash(ray.key, kSaltLight + li);
+        for (uint32_t k = 0; k < ns; ++k) {
+            d3 pos = D3(light.pos[0], light.pos[1], light.pos[2]);
+            if (light.radius != 0.0) { // light.rs:59-61 (cube-octant jitter)
+                unsigned long long sk = rng_hash(lkey, k);
+                d3 rnd = D3(rng_u01(sk, 0), rng_u01(sk, 1), rng_u01(sk, 2));
+                pos = pos + rnd * light.radius;
+            }
+            d3 ldir = pos - point;
+            double nrm = norm(ldir);
+            ldir = ldir / nrm;
+            double dist = nrm - 0.001;
+            d3 so = point + ldir * 0.001;
+            f3 filter = F3(1.0f, 1.0f, 1.0f);
+            Hit dummy;
+            cnt.shadow++;
+            if (traverse<true, STATS>(S, st, so, ldir, dist, dummy, filter, cnt)) continue; // shadowed
+            double dot_ldir_norm = dot(ldir, normal);
+            float dcoeff = (float)dot_ldir_norm;
+            dcoeff = dcoeff > 0.0f ? dcoeff : 0.0f;
+            f3 diffuse_color = F3(m.kd[0] * tex.x, m.kd[1] * tex.y, m.kd[2] * tex.z);
+            f3 diffuse = F3(diffuse_color.x * dcoeff, diffuse_color.y * dcoeff, diffuse_color.z * dcoeff);
+            d3 lproj = normal * dot_ldir_norm;
+            d3 rldir = normalize((-ldir) + lproj * 2.0);
+            float scoeff = (float)(-dot(rldir, ray.d));
+            if (scoeff > 0.0f) {
+                scoeff = powf(scoeff, m.shininess);
+                f3 sp = F3(m.ks[0] * scoeff, m.ks[1] * scoeff, m.ks[2] * scoeff);
+                acc.x = acc.x + light.color[0] * (filter.x * (diffuse.x + sp.x));
+                acc.y = acc.y + light.color[1] * (filter.y * (diffuse.y + sp.y));
+                acc.z = acc.z + light.color[2] * (filter.z * (diffuse.z + sp.z));
+            } else {
+                acc.x = acc.x + light.color[0] * (filter.x * diffuse.x);
+                acc.y = acc.y + light.color[1] * (filter.y * diffuse.y);
+                acc.z = acc.z + light.color[2] * (filter.z * diffuse.z);
+            }
+        }
+        float inv = 1.0f / (float)(light.racsample * light.racsample);
+        res.x = inv * acc.x + res.x; res.y = inv * acc.y + res.y; res.z = inv * acc.z + res.z;
+    }
+    f4 out; out.x = res.x; out.y = res.y; out.z = res.z; out.w = alpha;
+    return out;
+}
+
+// Continuation rays of one wave are appended to the next generation's queue with one atomic per
+// wave: ballot -> popcount prefix -> base offset broadcast.
+struct QueueOut {
+    RayQueue q;
+    uint32_t capacity;
+    uint32_t* count;          // count of the generation being produced
+    unsigned int* overflow;
+};
+
+NR_DEV void queue_store(const RayQueue& q, uint32_t i, const RayState& r) {
+    q.o[0][i] = r.o.x; q.o[1][i] = r.o.y; q.o[2][i] = r.o.z;
+    q.d[0][i] = r.d.x; q.d[1][i] = r.d.y; q.d[2][i] = r.d.z;
+    q.refr[i] = r.refr; q.energy[i] = r.energy; q.weight[i] = r.weight; q.pixel[i] = r.pixel; q.key[i] = r.key;
+}
+NR_DEV void queue_load(const RayQueue& q, uint32_t i, RayState& r) {
+    r.o = D3(q.o[0][i], q.o[1][i], q.o[2][i]);
+    r.d = D3(q.d[0][i], q.d[1][i], q.d[2][i]);
+    r.refr = q.refr[i]; r.energy = q.energy[i]; r.weight = q.weight[i]; r.pixel = q.pixel[i]; r.key = q.key[i];
+}
+
+NR_DEV void emit_children(const QueueOut& qo, bool has_a, const RayState& a, bool has_b, const RayState& b) {
+    unsigned long long ma = __ballot(has_a), mb = __ballot(has_b);
+    uint32_t na = (uint32_t)__popcll(ma), nb = (uint32_t)__popcll(mb);
+    if (na + nb == 0) return; // wave-uniform
+    uint32_t lane = __lane_id();
+    uint32_t base = 0;
+    if (lane == (uint32_t)(__ffsll((long long)(ma | mb)) - 1)) base = atomicAdd(qo.count, na + nb);
+    base = __shfl(base, __ffsll((long long)(ma | mb)) - 1);
+    unsigned long long lt = (1ULL << lane) - 1ULL;
+    if (has_a) {
+        uint32_t i = base + (uint32_t)__popcll(ma & lt);
+        if (i < qo.capacity) queue_store(qo.q, i, a); else atomicOr(qo.overflow, 1u);
+    }
+    if (has_b) {
+        uint32_t i = base + na + (uint32_t)__popcll(mb & lt);
+        if (i < qo.capacity) queue_store(qo.q, i, b); else atomicOr(qo.overflow, 1u);
+    }
+}
+
+// One step of the trace recursion unrolled (Scene::trace, scene.rs:163-193): closest hit, shade,
+// weight algebra, continuation rays.  Returns this ray's own weighted contribution to its pixel.
+// Must be called by every lane of the wave (inactive lanes pass active = false).
+template <bool STATS>
+NR_DEV f3 shade_and_continue(const DScene& S, Stack& st, bool active, const RayState& ray, uint32_t depth, uint32_t max_depth,
+                             const QueueOut& qo, Cnt& cnt) {
+    f3 contrib = F3(0.0f, 0.0f, 0.0f);
+    bool has_refl = false, has_refr = false;
+    RayState rr, rt;
+    rr = ray; rt = ray;
+    if (active) {
+        Hit hit; f3 nofilter = F3(1.0f, 1.0f, 1.0f);
+        if (!traverse<false, STATS>(S, st, ray.o, ray.d, kDblMax, hit, nofilter, cnt)) {
+            contrib = F3(S.background[0] * ray.weight, S.background[1] * ray.weight, S.background[2] * ray.weight);
+        } else {
+            Isect is; uint32_t node_id;
+            resolve_hit<false>(S, ray.o, ray.d, hit, is, node_id);
+            is.toi = hit.t;
+            if (STATS) cnt.hit++;
+            const NodeRec& sn = S.node_recs[node_id];
+            d3 pt = ray.o + ray.d * hit.t;
+            f4 obj = material_compute<STATS>(S, st, S.materials[sn.material_id], ray, pt, is, cnt);
+            bool may_recurse = depth < (uint32_t)kMaxGenerations && (max_depth == 0 || depth < max_depth);
+            float mix = sn.refl_mix;
+            float alpha = obj.w * sn.alpha;
+            float wa = alpha == 1.0f ? ray.weight : ray.weight * alpha; // scene.rs:183-190
+            // own term: obj.rgb * (1 - mix), scene.rs:179-180 (applied even when reflection is gated off)
+            float wo = wa * (1.0f - mix);
+            contrib = F3(obj.x * wo, obj.y * wo, obj.z * wo);
+            if (mix != 0.0f && ray.energy > 0.1f && may_recurse) { // trace_reflection, scene.rs:204-214
+                d3 nproj = is.n * dot(ray.d, is.n);
+                d3 rdir = ray.d - nproj * 2.0;
+                rr.o = pt + rdir * 0.001; rr.d = rdir; rr.refr = ray.refr; rr.energy = ray.energy - sn.refl_atenuation;
+                rr.weight = wa * mix; rr.key = rng_hash(ray.key, kSaltRefl); rr.pixel = ray.pixel;
+                has_refl = true; cnt.refl++;
+            }
+            if (alpha != 1.0f && may_recurse) { // trace_refraction, scene.rs:229-248
+                double n1, n2;
+                if (ray.refr == 1.0) { n1 = 1.0; n2 = sn.refr_coeff; } else { n1 = sn.refr_coeff; n2 = 1.0; }
+                d3 dir_along_normal = is.n * dot(ray.d, is.n);
+                d3 tangent = ray.d - dir_along_normal;
+                d3 new_dir = normalize(dir_along_normal + tangent * (n2 / n1));
+                rt.o = pt + new_dir * 0.001; rt.d = new_dir; rt.refr = n2; rt.energy = ray.energy;
+                rt.weight = ray.weight * (1.0f - alpha); rt.key = rng_hash(ray.key, kSaltRefr); rt.pixel = ray.pixel;
+                has_refr = true; cnt.refr++;
+            }
+        }
+    }
+    emit_children(qo, has_refl, rr, has_refr, rt);
+    return contrib;
+}
+
+// scene.rs:74-89: jitter, NDC, unproject by (P V)^-1, normalise.
+NR_DEV void generate_primary(const DRender& R, uint32_t i, uint32_t j, uint32_t s, uint32_t pixel_out, RayState& ray) {
+    unsigned long long pkey = rng_hash(R.seed, (unsigned long long)i + (unsigned long long)j * R.width);
+    unsigned long long skey = rng_hash(pkey, s);
+    double ox = (double)i, oy = (double)j;
+    if (R.window_width != 0.0) {
+        ox = ox + (rng_u01(skey, 0) - 0.5) * R.window_width;
+        oy = oy + (rng_u01(skey, 1) - 0.5) * R.window_width;
+    }
+    double dx = (ox / (double)R.width - 0.5) * 2.0;
+    double dy = -(oy / (double)R.height - 0.5) * 2.0;
+    double h[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) h[r] = R.m[r] * dx + R.m[4 + r] * dy + R.m[8 + r] * -1.0 + R.m[12 + r] * 1.0;
+    d3 eye = D3(h[0] / h[3], h[1] / h[3], h[2] / h[3]);
+    d3 e0 = D3(R.eye[0], R.eye[1], R.eye[2]);
+    ray.o = e0; ray.d = normalize(eye - e0); ray.refr = 1.0; ray.energy = 1.0f; ray.weight = 1.0f;
+    ray.key = rng_hash(skey, kSaltPath); ray.pixel = pixel_out;
+}
+
+} // namespace nrays
