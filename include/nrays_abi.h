@@ -179,8 +179,10 @@ typedef struct NraysStats {
     uint64_t tex_samples;     /* texture samples (4 taps each when bilinear) */
     uint32_t generations;     /* continuation generations executed */
     uint32_t instrumented;    /* 1 if the traversal counters above are valid */
-    double kernel_ms_primary; /* GPU time of the primary kernel (HIP events) */
-    double kernel_ms_total;   /* GPU time of the whole render, first launch to last */
+    double kernel_ms_primary; /* mean GPU time of the primary kernel launch (HIP events on the render stream) */
+    double kernel_ms_total;   /* mean GPU time of a whole render, first launch to last */
+    uint32_t frames_timed;    /* renders averaged in the two figures above (since the previous get_stats) */
+    uint32_t reserved;
 } NraysStats;
 
 typedef struct NraysScene NraysScene; /* opaque */
@@ -212,8 +214,14 @@ uint32_t nrays_tile_rows(const NraysRenderParams* params);
 int nrays_untile_device(const float* gathered, float* out_rgb_device, uint32_t width, uint32_t height,
                         uint32_t band_rows, uint32_t band_owners, void* hip_stream);
 
-/* Synchronises with the last render of `scene` and returns its counters. */
+/* Synchronises with the last render of `scene` and returns its counters; the kernel timings are
+ * averaged over the renders issued since the previous call (at most 256). */
 int nrays_get_stats(NraysScene* scene, NraysStats* out_stats);
+
+/* Counters of the PRIMARY kernel alone (first sample batch) of the last instrumented render: its
+ * primary rays, the shadow rays they spawned and the traversal work of both — the per-launch units
+ * behind bench.py's roofline figure. */
+int nrays_get_primary_kernel_stats(NraysScene* scene, NraysStats* out_stats);
 
 void nrays_scene_destroy(NraysScene* scene);
 

@@ -73,7 +73,7 @@ class NraysStats(C.Structure):
                 ("rays_shadow", C.c_uint64), ("node_tests", C.c_uint64), ("tri_tests", C.c_uint64),
                 ("prim_tests", C.c_uint64), ("hit_records", C.c_uint64), ("tex_samples", C.c_uint64),
                 ("generations", C.c_uint32), ("instrumented", C.c_uint32), ("kernel_ms_primary", C.c_double),
-                ("kernel_ms_total", C.c_double)]
+                ("kernel_ms_total", C.c_double), ("frames_timed", C.c_uint32), ("reserved", C.c_uint32)]
 
     def total_rays(self):
         return self.rays_primary + self.rays_reflection + self.rays_refraction + self.rays_shadow
@@ -97,6 +97,7 @@ HIP_SYMBOLS = {
     "nrays_tile_rows": (C.c_uint32, [C.POINTER(NraysRenderParams)]),
     "nrays_untile_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),
     "nrays_get_stats": (C.c_int, [C.c_void_p, C.POINTER(NraysStats)]),
+    "nrays_get_primary_kernel_stats": (C.c_int, [C.c_void_p, C.POINTER(NraysStats)]),
     "nrays_scene_destroy": (None, [C.c_void_p]),
     "nrays_last_error": (C.c_char_p, []),
     "nrays_abi_version": (C.c_uint32, []),

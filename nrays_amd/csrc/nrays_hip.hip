@@ -191,11 +191,16 @@ struct NraysScene {
     bool need_spill = false;
     float* d_frame = nullptr; size_t frame_floats = 0;
     hipStream_t own_stream = nullptr;
-    hipEvent_t ev_begin = nullptr, ev_primary_end = nullptr, ev_end = nullptr;
+    // ring of HIP event triples (frame begin, primary kernel begin/end, frame end) recorded on the render
+    // stream; nrays_get_stats averages the frames recorded since its previous call.
+    static constexpr int kRing = 256;
+    hipEvent_t ev_begin[kRing] = {}, ev_pbegin[kRing] = {}, ev_pend[kRing] = {}, ev_end[kRing] = {};
+    uint64_t frames_recorded = 0, frames_reported = 0;
+    DeviceCounters* d_counters_primary = nullptr; // snapshot taken right after the primary kernel
     hipStream_t last_stream = nullptr;
     bool have_last = false;
     NraysStats last;
-    uint64_t last_primary = 0;
+    uint64_t last_primary = 0, last_primary_first_batch = 0;
     uint32_t last_generations = 0;
     bool last_instrumented = false;
 };
@@ -293,8 +298,9 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
         else gens_static = std::min<uint32_t>(sc->host.reflection_generations, gen_cap);
     }
 
+    const int slot = (int)(sc->frames_recorded % NraysScene::kRing);
+    HIP_TRY(hipEventRecord(sc->ev_begin[slot], stream));
     HIP_TRY(hipMemsetAsync(sc->d_counters, 0, sizeof(DeviceCounters), stream));
-    HIP_TRY(hipEventRecord(sc->ev_begin, stream));
     uint32_t generations_run = 0;
     bool first_primary = true;
     for (uint32_t s0 = 0; s0 < p->ray_per_pixel; s0 += batch) {
@@ -303,10 +309,15 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
         if (continuations) HIP_TRY(hipMemsetAsync(sc->d_counts, 0, (kMaxGenerations + 2) * sizeof(uint32_t), stream));
         QueueOut qo; qo.q = sc->queue[1].q; qo.capacity = continuations ? sc->queue_capacity : 0; qo.count = sc->d_counts + 1;
         qo.overflow = &sc->d_counters->overflow;
+        if (first_primary) HIP_TRY(hipEventRecord(sc->ev_pbegin[slot], stream));
         if (instrumented) hipLaunchKernelGGL(k_primary<true>, dim3(grid_primary), dim3(kBlock), 0, stream, sc->d, R, qo, d_out, sc->d_counters, sc->d_spill, tiles_x, tiles_y, work_items);
         else hipLaunchKernelGGL(k_primary<false>, dim3(grid_primary), dim3(kBlock), 0, stream, sc->d, R, qo, d_out, sc->d_counters, sc->d_spill, tiles_x, tiles_y, work_items);
         HIP_TRY(hipGetLastError());
-        if (first_primary) { HIP_TRY(hipEventRecord(sc->ev_primary_end, stream)); first_primary = false; }
+        if (first_primary) {
+            HIP_TRY(hipEventRecord(sc->ev_pend[slot], stream));
+            if (instrumented) HIP_TRY(hipMemcpyAsync(sc->d_counters_primary, sc->d_counters, sizeof(DeviceCounters), hipMemcpyDeviceToDevice, stream));
+            first_primary = false;
+        }
 
         uint32_t gmax = host_controlled ? gen_cap : gens_static;
         for (uint32_t g = 1; g <= gmax; ++g) {
@@ -332,13 +343,15 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
         hipLaunchKernelGGL(k_resolve, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_out, n, (float)p->ray_per_pixel);
         HIP_TRY(hipGetLastError());
     }
-    HIP_TRY(hipEventRecord(sc->ev_end, stream));
+    HIP_TRY(hipEventRecord(sc->ev_end[slot], stream));
+    sc->frames_recorded++;
     sc->last_stream = stream; sc->have_last = true;
     // owned rows only (padding rows of the last band carry no rays)
     uint64_t owned_rows = 0;
     if (p->band_rows == 0 || p->band_owners <= 1) owned_rows = p->height;
     else for (uint32_t j = 0; j < p->height; ++j) if (((j / p->band_rows) % p->band_owners) == p->band_owner) ++owned_rows;
     sc->last_primary = owned_rows * p->width * p->ray_per_pixel;
+    sc->last_primary_first_batch = owned_rows * p->width * std::min<uint32_t>(batch, p->ray_per_pixel);
     sc->last_generations = generations_run;
     sc->last_instrumented = instrumented;
     return NRAYS_OK;
@@ -395,14 +408,17 @@ int nrays_scene_create(const NraysSceneDesc* desc, NraysScene** out_scene) {
     std::vector<BvhNode>().swap(h.nodes); std::vector<TriRec>().swap(h.tris); std::vector<TriUv>().swap(h.triuvs);
 
     if (hipMalloc((void**)&sc->d_counts, (kMaxGenerations + 2) * sizeof(uint32_t)) != hipSuccess ||
-        hipMalloc((void**)&sc->d_counters, sizeof(DeviceCounters)) != hipSuccess)
+        hipMalloc((void**)&sc->d_counters, sizeof(DeviceCounters)) != hipSuccess ||
+        hipMalloc((void**)&sc->d_counters_primary, sizeof(DeviceCounters)) != hipSuccess)
         return bail(fail(NRAYS_ERR_OOM, "counter allocation failed"));
     if (hipMemset(sc->d_counts, 0, (kMaxGenerations + 2) * sizeof(uint32_t)) != hipSuccess ||
         hipMemset(sc->d_counters, 0, sizeof(DeviceCounters)) != hipSuccess)
         return bail(fail(NRAYS_ERR_HIP, "counter memset failed"));
-    if (hipStreamCreate(&sc->own_stream) != hipSuccess || hipEventCreate(&sc->ev_begin) != hipSuccess ||
-        hipEventCreate(&sc->ev_primary_end) != hipSuccess || hipEventCreate(&sc->ev_end) != hipSuccess)
-        return bail(fail(NRAYS_ERR_HIP, "stream/event creation failed"));
+    if (hipStreamCreate(&sc->own_stream) != hipSuccess) return bail(fail(NRAYS_ERR_HIP, "stream creation failed"));
+    for (int k = 0; k < NraysScene::kRing; ++k)
+        if (hipEventCreate(&sc->ev_begin[k]) != hipSuccess || hipEventCreate(&sc->ev_pbegin[k]) != hipSuccess ||
+            hipEventCreate(&sc->ev_pend[k]) != hipSuccess || hipEventCreate(&sc->ev_end[k]) != hipSuccess)
+            return bail(fail(NRAYS_ERR_HIP, "event creation failed"));
     *out_scene = sc;
     return NRAYS_OK;
 }
@@ -417,9 +433,13 @@ void nrays_scene_destroy(NraysScene* sc) {
     if (sc->d_counters) (void)hipFree(sc->d_counters);
     if (sc->d_spill) (void)hipFree(sc->d_spill);
     if (sc->d_frame) (void)hipFree(sc->d_frame);
-    if (sc->ev_begin) (void)hipEventDestroy(sc->ev_begin);
-    if (sc->ev_primary_end) (void)hipEventDestroy(sc->ev_primary_end);
-    if (sc->ev_end) (void)hipEventDestroy(sc->ev_end);
+    if (sc->d_counters_primary) (void)hipFree(sc->d_counters_primary);
+    for (int k = 0; k < NraysScene::kRing; ++k) {
+        if (sc->ev_begin[k]) (void)hipEventDestroy(sc->ev_begin[k]);
+        if (sc->ev_pbegin[k]) (void)hipEventDestroy(sc->ev_pbegin[k]);
+        if (sc->ev_pend[k]) (void)hipEventDestroy(sc->ev_pend[k]);
+        if (sc->ev_end[k]) (void)hipEventDestroy(sc->ev_end[k]);
+    }
     if (sc->own_stream) (void)hipStreamDestroy(sc->own_stream);
     delete sc;
 }
@@ -432,6 +452,12 @@ int nrays_render_device_instrumented(NraysScene* scene, const NraysRenderParams*
     return render_impl(scene, params, out_rgb_device, (hipStream_t)hip_stream, true);
 }
 
+static void fill_counters(NraysStats* out, const DeviceCounters& c) {
+    out->rays_reflection = c.rays_reflection; out->rays_refraction = c.rays_refraction; out->rays_shadow = c.rays_shadow;
+    out->node_tests = c.node_tests; out->tri_tests = c.tri_tests; out->prim_tests = c.prim_tests;
+    out->hit_records = c.hit_records; out->tex_samples = c.tex_samples;
+}
+
 int nrays_get_stats(NraysScene* sc, NraysStats* out) {
     if (!sc || !out) return fail(NRAYS_ERR_BAD_ARG, "null argument");
     std::memset(out, 0, sizeof *out);
@@ -441,14 +467,37 @@ int nrays_get_stats(NraysScene* sc, NraysStats* out) {
     DeviceCounters c;
     HIP_TRY(hipMemcpy(&c, sc->d_counters, sizeof c, hipMemcpyDeviceToHost));
     out->rays_primary = sc->last_primary;
-    out->rays_reflection = c.rays_reflection; out->rays_refraction = c.rays_refraction; out->rays_shadow = c.rays_shadow;
-    out->node_tests = c.node_tests; out->tri_tests = c.tri_tests; out->prim_tests = c.prim_tests;
-    out->hit_records = c.hit_records; out->tex_samples = c.tex_samples;
+    fill_counters(out, c);
     out->generations = sc->last_generations; out->instrumented = sc->last_instrumented ? 1u : 0u;
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, sc->ev_begin, sc->ev_primary_end) == hipSuccess) out->kernel_ms_primary = ms;
-    if (hipEventElapsedTime(&ms, sc->ev_begin, sc->ev_end) == hipSuccess) out->kernel_ms_total = ms;
+    // average the event timings of the frames recorded since the previous call (at most kRing)
+    uint64_t first = sc->frames_reported;
+    if (sc->frames_recorded - first > (uint64_t)NraysScene::kRing) first = sc->frames_recorded - NraysScene::kRing;
+    double sum_p = 0.0, sum_t = 0.0; uint64_t n = 0;
+    for (uint64_t f = first; f < sc->frames_recorded; ++f) {
+        int k = (int)(f % NraysScene::kRing);
+        float ms_p = 0.f, ms_t = 0.f;
+        if (hipEventElapsedTime(&ms_p, sc->ev_pbegin[k], sc->ev_pend[k]) == hipSuccess &&
+            hipEventElapsedTime(&ms_t, sc->ev_begin[k], sc->ev_end[k]) == hipSuccess) { sum_p += ms_p; sum_t += ms_t; ++n; }
+    }
+    sc->frames_reported = sc->frames_recorded;
+    if (n) { out->kernel_ms_primary = sum_p / (double)n; out->kernel_ms_total = sum_t / (double)n; }
+    out->frames_timed = (uint32_t)n;
     if (c.overflow) return fail(NRAYS_ERR_QUEUE_OVERFLOW, "continuation-ray queue overflow: image is incomplete");
+    return NRAYS_OK;
+}
+
+int nrays_get_primary_kernel_stats(NraysScene* sc, NraysStats* out) {
+    if (!sc || !out) return fail(NRAYS_ERR_BAD_ARG, "null argument");
+    std::memset(out, 0, sizeof *out);
+    if (!sc->have_last || !sc->last_instrumented) return fail(NRAYS_ERR_BAD_ARG, "the last render was not instrumented");
+    HIP_TRY(hipSetDevice(sc->device));
+    HIP_TRY(hipStreamSynchronize(sc->last_stream));
+    DeviceCounters c;
+    HIP_TRY(hipMemcpy(&c, sc->d_counters_primary, sizeof c, hipMemcpyDeviceToHost));
+    out->rays_primary = sc->last_primary_first_batch;
+    fill_counters(out, c);
+    out->rays_reflection = 0; out->rays_refraction = 0; // continuation rays are traced by the bounce kernels
+    out->instrumented = 1;
     return NRAYS_OK;
 }
 

@@ -1,0 +1,71 @@
+"""Multi-GPU framebuffer tiling: one process per GPU, rows dealt to ranks in bands.
+
+The reference's only parallelism is a contiguous static split of the pixel range over CPU threads
+(src/scene.rs:49-66).  Here the scene is replicated on every GPU, band b of `band_rows` rows is
+rendered by rank b % world, every rank renders into a compact tile buffer, and ONE collective — a
+gather to rank 0 over RCCL/xGMI (every peer has its own direct link to GPU 0, so no ring) — is the
+only exchange step; rank 0 then un-permutes the bands with the k_untile HIP kernel.
+The RNG is keyed by the global pixel index, so the frame does not depend on the number of GPUs.
+"""
+import ctypes as C
+
+from . import abi
+
+DEFAULT_BAND_ROWS = 16  # one 16x16 workgroup tile high
+
+
+def band_owner(row, band_rows, world):
+    return (row // band_rows) % world
+
+
+def owned_rows(height, band_rows, rank, world):
+    """Global row indices rendered by `rank`, in the order they appear in its compact tile buffer."""
+    return [j for j in range(height) if band_owner(j, band_rows, world) == rank]
+
+
+def tile_rows(height, band_rows, world):
+    """Rows of every rank's compact buffer (bands are padded so that all ranks gather equal sizes)."""
+    if world <= 1:
+        return height
+    nb = (height + band_rows - 1) // band_rows
+    return ((nb + world - 1) // world) * band_rows
+
+
+def tile_params(params, rank, world, band_rows=DEFAULT_BAND_ROWS):
+    """Copy of `params` restricted to the bands of `rank`."""
+    p = abi.NraysRenderParams()
+    C.memmove(C.byref(p), C.byref(params), C.sizeof(p))
+    if world > 1:
+        p.band_rows, p.band_owner, p.band_owners = band_rows, rank, world
+    else:
+        p.band_rows, p.band_owner, p.band_owners = 0, 0, 1
+    return p
+
+
+def gather_tiles(tile, rank, world, group=None):
+    """The single exchange step: gathers every rank's compact tile on rank 0 ((world, rows, W, 3) there,
+    None elsewhere).  `tile` is a torch tensor on the rank's device (CPU tensors work with gloo)."""
+    import torch
+    import torch.distributed as dist
+    if world == 1:
+        return tile.unsqueeze(0)
+    if rank == 0:
+        out = torch.empty((world,) + tuple(tile.shape), dtype=tile.dtype, device=tile.device)
+        dist.gather(tile, gather_list=list(out.unbind(0)), dst=0, group=group)
+        return out
+    dist.gather(tile, gather_list=None, dst=0, group=group)
+    return None
+
+
+def untile_device(gathered, width, height, band_rows, world, out=None, stream=None):
+    """Band interleave -> row-major frame on the GPU (k_untile).  `gathered` is the (world, rows, W, 3)
+    CUDA tensor from gather_tiles on rank 0."""
+    import torch
+    lib = abi.load_hip_lib()
+    if out is None:
+        out = torch.empty((height, width, 3), dtype=torch.float32, device=gathered.device)
+    if stream is None:
+        stream = torch.cuda.current_stream().cuda_stream
+    abi.check(lib.nrays_untile_device(C.c_void_p(gathered.data_ptr()), C.c_void_p(out.data_ptr()), width, height,
+                                      band_rows if world > 1 else height, world, C.c_void_p(stream)))
+    return out
