@@ -104,7 +104,8 @@ HIP_SYMBOLS = {
 }
 
 _REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-HIP_LIB_PATH = os.path.join(_REPO, "nrays_amd", "lib", "libnrays_hip.so")
+# NRAYS_HIP_LIB overrides the library path (kernel A/B tuning with tools/kbench.py only).
+HIP_LIB_PATH = os.environ.get("NRAYS_HIP_LIB") or os.path.join(_REPO, "nrays_amd", "lib", "libnrays_hip.so")
 HOST_LIB_PATH = os.path.join(_REPO, "nrays_amd", "lib", "libnrays_host.so")
 
 _hip_lib = None

@@ -116,6 +116,8 @@ struct DScene {
     const Instance* instances;        // closest-hit TLAS leaves (+ planes at the end)
     const Instance* shadow_instances; // shadow TLAS leaves (+ planes at the end)
     const NodeRec* node_recs;
+    const double* node_aabbs;         // 6 f64 per scene node: world AABB exactly as the reference computes
+                                      // geometry.bounding_volume(&transform) (scene_node.rs:41); gates accepted hits
     const MaterialRec* materials;
     const TextureRec* textures;
     const LightRec* lights;

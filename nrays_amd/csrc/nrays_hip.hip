@@ -385,6 +385,7 @@ int nrays_scene_create(const NraysSceneDesc* desc, NraysScene** out_scene) {
     if ((rc = upload(sc, h.instances, &sc->d.instances)) != NRAYS_OK) return bail(rc);
     if ((rc = upload(sc, h.shadow_instances, &sc->d.shadow_instances)) != NRAYS_OK) return bail(rc);
     if ((rc = upload(sc, h.node_recs, &sc->d.node_recs)) != NRAYS_OK) return bail(rc);
+    if ((rc = upload(sc, h.node_aabbs, &sc->d.node_aabbs)) != NRAYS_OK) return bail(rc);
     if ((rc = upload(sc, h.materials, &sc->d.materials)) != NRAYS_OK) return bail(rc);
     if ((rc = upload(sc, h.lights, &sc->d.lights)) != NRAYS_OK) return bail(rc);
     if ((rc = upload(sc, h.planes, &sc->d.planes)) != NRAYS_OK) return bail(rc);

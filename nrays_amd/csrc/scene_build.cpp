@@ -46,6 +46,76 @@ PrimBounds world_box(const double R[9], const double t[3], const double c[3], co
 
 bool shape_has_uv(uint32_t kind) { return kind == NRAYS_SHAPE_BALL || kind == NRAYS_SHAPE_CUBOID; }
 
+// ---- world AABB of a node, in the reference's own arithmetic --------------------------------
+// SceneNode::new stores geometry.bounding_volume(&transform) (scene_node.rs:41) and Scene::trace only
+// casts a node whose AABB the ray hits (scene.rs:276).  The kernels cull with conservative f32 boxes
+// and then apply THIS box, with ncollide's exact slab test, to every accepted hit, so the set of
+// candidate hits is the reference's.  Formulas: ncollide3d bounding_volume impls (SURVEY B-1..B-9).
+struct V3 { double x, y, z; };
+V3 mat_vec(const double R[9], V3 v) {
+    return {R[0] * v.x + R[1] * v.y + R[2] * v.z, R[3] * v.x + R[4] * v.y + R[5] * v.z, R[6] * v.x + R[7] * v.y + R[8] * v.z};
+}
+V3 mat_t_vec(const double R[9], V3 v) {
+    return {R[0] * v.x + R[3] * v.y + R[6] * v.z, R[1] * v.x + R[4] * v.y + R[7] * v.z, R[2] * v.x + R[5] * v.y + R[8] * v.z};
+}
+V3 mat_abs_vec(const double R[9], V3 v) {
+    return {std::fabs(R[0]) * v.x + std::fabs(R[1]) * v.y + std::fabs(R[2]) * v.z,
+            std::fabs(R[3]) * v.x + std::fabs(R[4]) * v.y + std::fabs(R[5]) * v.z,
+            std::fabs(R[6]) * v.x + std::fabs(R[7]) * v.y + std::fabs(R[8]) * v.z};
+}
+V3 support_local(const NraysNode& d, V3 dir) { // SupportMap of Cylinder / Cone / Capsule (axis = local Y)
+    double hh = d.params[0], r = d.params[1];
+    V3 res = {dir.x, 0.0, dir.z};
+    double n = std::sqrt(res.x * res.x + res.y * res.y + res.z * res.z);
+    if (d.shape_kind == NRAYS_SHAPE_CYLINDER) {
+        if (n == 0.0) res = {0, 0, 0}; else res = {res.x / n * r, res.y / n * r, res.z / n * r};
+        res.y = std::copysign(hh, dir.y);
+        return res;
+    }
+    if (d.shape_kind == NRAYS_SHAPE_CONE) {
+        if (n == 0.0) return {0.0, std::copysign(hh, dir.y), 0.0};
+        res = {res.x / n * r, res.y / n * r, res.z / n * r}; res.y = -hh;
+        if (dir.x * res.x + dir.y * res.y + dir.z * res.z < dir.y * hh) return {0.0, hh, 0.0};
+        return res;
+    }
+    return {0.0 + dir.x * r, std::copysign(hh, dir.y) + dir.y * r, 0.0 + dir.z * r};
+}
+void node_world_aabb(const NraysNode& n, const double R[9], const float mesh_mn[3], const float mesh_mx[3], double out[6]) {
+    const double* t = n.translation;
+    switch (n.shape_kind) {
+    case NRAYS_SHAPE_BALL:
+        for (int a = 0; a < 3; ++a) { out[a] = t[a] - n.params[0]; out[3 + a] = t[a] + n.params[0]; }
+        return;
+    case NRAYS_SHAPE_CUBOID: {
+        V3 h = mat_abs_vec(R, {n.params[0], n.params[1], n.params[2]});
+        out[0] = t[0] - h.x; out[1] = t[1] - h.y; out[2] = t[2] - h.z; out[3] = t[0] + h.x; out[4] = t[1] + h.y; out[5] = t[2] + h.z;
+        return;
+    }
+    case NRAYS_SHAPE_PLANE:
+        for (int a = 0; a < 3; ++a) { out[a] = -std::numeric_limits<double>::max(); out[3 + a] = std::numeric_limits<double>::max(); }
+        return;
+    case NRAYS_SHAPE_TRIMESH: {
+        V3 c = {((double)mesh_mn[0] + (double)mesh_mx[0]) * 0.5, ((double)mesh_mn[1] + (double)mesh_mx[1]) * 0.5, ((double)mesh_mn[2] + (double)mesh_mx[2]) * 0.5};
+        V3 h = {((double)mesh_mx[0] - (double)mesh_mn[0]) * 0.5, ((double)mesh_mx[1] - (double)mesh_mn[1]) * 0.5, ((double)mesh_mx[2] - (double)mesh_mn[2]) * 0.5};
+        V3 rc = mat_vec(R, c);
+        V3 wc = {rc.x + t[0], rc.y + t[1], rc.z + t[2]};
+        V3 wh = mat_abs_vec(R, h);
+        out[0] = wc.x - wh.x; out[1] = wc.y - wh.y; out[2] = wc.z - wh.z; out[3] = wc.x + wh.x; out[4] = wc.y + wh.y; out[5] = wc.z + wh.z;
+        return;
+    }
+    default:
+        for (int i = 0; i < 3; ++i) {
+            V3 e = {i == 0 ? 1.0 : 0.0, i == 1 ? 1.0 : 0.0, i == 2 ? 1.0 : 0.0};
+            V3 ld = mat_t_vec(R, e);
+            V3 sp = mat_vec(R, support_local(n, ld));
+            V3 sn = mat_vec(R, support_local(n, {-ld.x, -ld.y, -ld.z}));
+            double spv[3] = {sp.x + t[0], sp.y + t[1], sp.z + t[2]}, snv[3] = {sn.x + t[0], sn.y + t[1], sn.z + t[2]};
+            out[3 + i] = spv[i]; out[i] = snv[i];
+        }
+        return;
+    }
+}
+
 struct Blas {
     int32_t root;
     float mn[3], mx[3]; // local bounds
@@ -175,6 +245,21 @@ int build_host_scene(const NraysSceneDesc* d, HostScene& out, std::string& err) 
         r.refl_mix = n.refl_mix; r.refl_atenuation = n.refl_atenuation; r.alpha = n.alpha; r.material_id = n.material_id;
         r.refr_coeff = n.refr_coeff; r.pad[0] = has_uv ? 1u : 0u; r.pad[1] = 0;
         out.node_recs.push_back(r);
+        {
+            float mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
+            if (n.shape_kind == NRAYS_SHAPE_TRIMESH) { // local AABB = union of the faces' vertices (TriMesh BVT root)
+                const NraysMesh& m = d->meshes[n.mesh_id];
+                for (int a = 0; a < 3; ++a) { mn[a] = std::numeric_limits<float>::infinity(); mx[a] = -std::numeric_limits<float>::infinity(); }
+                for (uint32_t t = 0; t < m.num_triangles * 3u; ++t) {
+                    uint32_t vi = m.indices[t];
+                    if (vi >= m.num_vertices) { err = "triangle index out of range"; return NRAYS_ERR_BAD_ARG; }
+                    for (int a = 0; a < 3; ++a) { float f = (float)m.vertices[3 * (size_t)vi + a]; mn[a] = std::min(mn[a], f); mx[a] = std::max(mx[a], f); }
+                }
+            }
+            double bb[6];
+            node_world_aabb(n, info[i].R, mn, mx, bb);
+            out.node_aabbs.insert(out.node_aabbs.end(), bb, bb + 6);
+        }
     }
     if (out.any_reflective) {
         uint32_t k = 0; float e = 1.0f;

@@ -22,6 +22,7 @@ struct HostScene {
     std::vector<Instance> shadow_instances;  // shadow TLAS order, planes appended at the end
     std::vector<int32_t> planes, shadow_planes;
     std::vector<NodeRec> node_recs;
+    std::vector<double> node_aabbs;          // 6 per node (mins, maxs), reference arithmetic
     std::vector<MaterialRec> materials;
     std::vector<HostTexture> textures;
     std::vector<LightRec> lights;

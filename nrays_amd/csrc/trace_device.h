@@ -515,6 +515,38 @@ NR_DEV float box_entry(float mnx, float mny, float mnz, float mxx, float mxy, fl
     return (tn * 0.9999995f <= tf * 1.0000005f) ? tn : -1.0f;
 }
 
+// ncollide ray_aabb (AABB::toi_with_ray, solid = true; SURVEY B-3) as a predicate, in f64 and in the
+// reference's operation order.  The reference only casts a node / tests a triangle whose AABB this
+// test accepts (src/scene.rs:276 and the TriMesh BVT), so it is applied to every ACCEPTED hit; the
+// conservative f32 culling above only decides what is looked at.
+NR_DEV bool aabb_pass(double mnx, double mny, double mnz, double mxx, double mxy, double mxz, d3 o, d3 d) {
+    double tmax = kDblMax, tmin = -kDblMax;
+    const double mn[3] = {mnx, mny, mnz}, mx[3] = {mxx, mxy, mxz};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        double dd = comp(d, i), oo = comp(o, i);
+        if (dd == 0.0) {
+            if (oo < mn[i] || oo > mx[i]) return false;
+        } else {
+            double denom = 1.0 / dd;
+            double tn = (mn[i] - oo) * denom, tf = (mx[i] - oo) * denom;
+            if (tn > tf) { double s = tn; tn = tf; tf = s; }
+            if (tn > tmin) tmin = tn;
+            if (tf < tmax) tmax = tf;
+            if (tmax < 0.0 || tmin > tmax) return false;
+        }
+    }
+    return true;
+}
+NR_DEV bool node_aabb_pass(const DScene& S, uint32_t node_id, d3 o, d3 d) {
+    const double* b = S.node_aabbs + 6 * (size_t)node_id;
+    return aabb_pass(b[0], b[1], b[2], b[3], b[4], b[5], o, d);
+}
+NR_DEV bool tri_aabb_pass(d3 a, d3 b, d3 c, d3 o, d3 d) {
+    return aabb_pass(fmin(a.x, fmin(b.x, c.x)), fmin(a.y, fmin(b.y, c.y)), fmin(a.z, fmin(b.z, c.z)),
+                     fmax(a.x, fmax(b.x, c.x)), fmax(a.y, fmax(b.y, c.y)), fmax(a.z, fmax(b.z, c.z)), o, d);
+}
+
 // Reconstructs the full intersection record of a finished closest-hit query.
 template <bool SHADOW>
 NR_DEV void resolve_hit(const DScene& S, d3 o, d3 d, const Hit& h, Isect& out, uint32_t& node_id) {
@@ -640,7 +672,7 @@ NR_DEV bool traverse(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, Hit&
             }
             if (STATS) cnt.prim++;
             Isect is;
-            if (cast_analytic(in, o, d, is)) {
+            if (cast_analytic(in, o, d, is) && (in.kind == NRAYS_SHAPE_PLANE || node_aabb_pass(S, (uint32_t)in.node_id, o, d))) {
                 if (SHADOW) {
                     if (is.toi <= tlimit && shadow_node_hit<STATS>(S, (uint32_t)in.node_id, is, filter, cnt)) return true;
                 } else {
@@ -657,7 +689,9 @@ NR_DEV bool traverse(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, Hit&
             float4 t0 = tq[0], t1 = tq[1], t2 = tq[2];
             if (STATS) cnt.tri++;
             double toi;
-            if (cast_triangle(D3(t0.x, t0.y, t0.z), D3(t1.x, t1.y, t1.z), D3(t2.x, t2.y, t2.z), co, cd, toi, nullptr, nullptr)) {
+            d3 va = D3(t0.x, t0.y, t0.z), vb = D3(t1.x, t1.y, t1.z), vc = D3(t2.x, t2.y, t2.z);
+            if (cast_triangle(va, vb, vc, co, cd, toi, nullptr, nullptr) && tri_aabb_pass(va, vb, vc, co, cd) &&
+                node_aabb_pass(S, __float_as_uint(t0.w), o, d)) {
                 if (SHADOW && (cur_flags & kInstAnyHit)) { if (toi <= tlimit) return true; }
                 else {
                     unsigned long long key = SHADOW ? (unsigned long long)__float_as_uint(t1.w)

@@ -238,8 +238,13 @@ typedef struct CostFn {
 } CostFn;
 
 /* ncollide best_first_search (SURVEY B-2) with the deterministic tie-break D-2: a candidate with
- * cost == best replaces the incumbent iff its leaf index is smaller; volumes are pruned only when
- * cost > best so that such candidates are always reached. */
+ * cost == best replaces the incumbent iff its leaf index is smaller.  The reference prunes a volume
+ * when its cost >= best, which makes the winner among equal-toi candidates depend on BinaryHeap
+ * order and on last-bit rounding of the AABB entry distance; here volumes are pruned only when
+ * cost > best * (1 + 1e-12), so the result is exactly
+ *     lexicographic min (toi, leaf index) over { leaves whose AABB test passes and whose cast hits },
+ * a set that does not depend on the tree shape (the fp slab test is monotone under box inclusion). */
+#define PRUNE_SLACK(best) ((best) < DBL_MAX / 2 ? (best) * (1.0 + 1e-12) : (best))
 static int bvt_best_first(const Bvt* t, CostFn* fn, int* out_leaf, Inter* out_inter, double* out_cost) {
     if (t->root < 0) return 0;
     double best = DBL_MAX;
@@ -250,12 +255,12 @@ static int bvt_best_first(const Bvt* t, CostFn* fn, int* out_leaf, Inter* out_in
     if (fn->bv_cost(fn, &t->nodes[t->root].bv, &c)) heap_push(&h, c, t->root);
     while (h.n > 0) {
         HeapItem it = heap_pop(&h);
-        if (it.cost > best) break;
+        if (it.cost > PRUNE_SLACK(best)) break;
         const BvtNode* nd = &t->nodes[it.node];
         if (nd->leaf < 0) {
             int ch[2] = {nd->left, nd->right};
             for (int k = 0; k < 2; ++k)
-                if (fn->bv_cost(fn, &t->nodes[ch[k]].bv, &c) && c <= best) heap_push(&h, c, ch[k]);
+                if (fn->bv_cost(fn, &t->nodes[ch[k]].bv, &c) && c <= PRUNE_SLACK(best)) heap_push(&h, c, ch[k]);
         } else {
             Inter in; double cost;
             if (fn->b_cost(fn, nd->leaf, &cost, &in)) {
@@ -1121,7 +1126,9 @@ static int brute_cast(const OScene* sc, const Ray* ray, Inter* bi, int* node, Co
     for (int i = 0; i < sc->nnodes; ++i) {
         const ONode* n = &sc->nodes[i];
         Inter in; int hit = 0;
+        double dummy;
         memset(&in, 0, sizeof in);
+        if (!aabb_toi(&n->aabb, ray, &dummy)) continue; /* the node's world AABB gates its cast (scene.rs:276) */
         if (n->d.shape_kind == NRAYS_SHAPE_TRIMESH) {
             Ray l = iso_inv_ray(&n->iso, ray);
             double bt = DBL_MAX;
@@ -1129,7 +1136,12 @@ static int brute_cast(const OScene* sc, const Ray* ray, Inter* bi, int* node, Co
             for (int t = 0; t < me->ntris; ++t) {
                 double toi, bary[3]; v3 nn;
                 uint32_t i0 = me->idx[3 * t], i1 = me->idx[3 * t + 1], i2 = me->idx[3 * t + 2];
-                if (cast_triangle(mesh_vert(me, i0), mesh_vert(me, i1), mesh_vert(me, i2), &l, &toi, &nn, bary) && toi < bt) {
+                v3 pa = mesh_vert(me, i0), pb = mesh_vert(me, i1), pc = mesh_vert(me, i2);
+                AABB tb;
+                tb.mins = V(fmin(pa.x, fmin(pb.x, pc.x)), fmin(pa.y, fmin(pb.y, pc.y)), fmin(pa.z, fmin(pb.z, pc.z)));
+                tb.maxs = V(fmax(pa.x, fmax(pb.x, pc.x)), fmax(pa.y, fmax(pb.y, pc.y)), fmax(pa.z, fmax(pb.z, pc.z)));
+                if (!aabb_toi(&tb, &l, &dummy)) continue; /* the triangle's own AABB gates its test (TriMesh BVT leaf) */
+                if (cast_triangle(pa, pb, pc, &l, &toi, &nn, bary) && toi < bt) {
                     bt = toi; hit = 1; in.toi = toi; in.normal = iso_rot(&n->iso, nn); in.prim = t;
                     in.has_uv = me->uvs != NULL;
                     if (me->uvs) {

@@ -167,3 +167,20 @@ def test_full_size_balls_properties(gpu):
     tile, _ = hip_render(sc, p)
     rows = [j for j in range(H) if (j // 16) % 2 == 1]
     assert np.array_equal(tile[: len(rows)], full[rows])
+
+
+def test_sponza_standin_including_the_symmetry_plane_ties(gpu):
+    """The stand-in has a column of coincident pole vertices exactly in the camera's symmetry plane:
+    the centre pixel column (d.z == 0) hits ~160 triangles at the same toi.  Reference semantics =
+    lexicographic min (toi, node, triangle) over hits whose node AABB and triangle AABB pass the exact
+    ncollide slab test; the GPU culls conservatively in f32 and gates accepted hits with those tests."""
+    from tests import standins
+    sc, cam = standins.sponza_scene()
+    compare(sc, cam, 160, 90, threads=32)
+    compare(sc, cam, 96, 54, threads=32, max_depth=2)
+
+
+def test_hairball_standin_small(gpu):
+    from tests import standins
+    sc, cam = standins.hairball_scene(strands=400)
+    compare(sc, cam, 128, 128, threads=32)
