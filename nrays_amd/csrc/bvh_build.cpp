@@ -38,6 +38,10 @@ struct Box {
 };
 
 constexpr int kBins = 16;
+#ifndef NR_PRIM_COST
+#define NR_PRIM_COST 0.7f
+#endif
+constexpr float kPrimCost = NR_PRIM_COST;
 
 struct Builder {
     const std::vector<PrimBounds>& prims;
@@ -94,9 +98,9 @@ struct Builder {
             }
         }
         if ((int)count <= max_leaf) {
-            // leaf cost (intersection cost 1 per primitive, traversal cost 1 per node, in half-area units)
-            float leaf_cost = bounds.half_area() * (float)count;
-            float split_cost = best_axis < 0 ? std::numeric_limits<float>::infinity() : best_cost + bounds.half_area() * 1.0f;
+            // SAH: an exact f64 ray/triangle test costs about kPrimCost times a (two-box, f32) node visit
+            float leaf_cost = bounds.half_area() * (float)count * kPrimCost;
+            float split_cost = best_axis < 0 ? std::numeric_limits<float>::infinity() : best_cost * kPrimCost + bounds.half_area() * 1.0f;
             if (!(split_cost < leaf_cost)) return make_leaf_ref(first, count);
         }
         uint32_t mid;

@@ -91,14 +91,16 @@ struct LightRec { // src/light.rs:8-13
 struct DeviceCounters {
     unsigned long long rays_reflection, rays_refraction, rays_shadow;
     unsigned long long node_tests, tri_tests, prim_tests, hit_records, tex_samples;
-    unsigned int overflow; // set when a continuation queue ran out of capacity
-    unsigned int pad;
+    unsigned int overflow;  // set when a continuation queue ran out of capacity
+    unsigned int max_depth; // deepest trace depth reached (= number of continuation generations)
 };
 
 constexpr int kMaxGenerations = 64; // hard cap on trace depth (reference recursion is unbounded, scene.rs:246)
 
-// Continuation-ray queue (SoA in HBM): generation g reads queue[g & 1] with count[g] entries and
-// appends to queue[(g + 1) & 1] / count[g + 1] through wave ballot + prefix-sum compaction.
+// Continuation-ray queue (SoA in HBM).  A hit that spawns both a reflection and a refraction keeps
+// the reflection in registers and appends the refraction here through wave ballot + prefix-sum
+// compaction; round r of k_bounce reads queue[r & 1] with count[r] entries and appends to
+// queue[(r + 1) & 1] / count[r + 1].
 struct RayQueue {
     double* o[3];
     double* d[3];
@@ -106,6 +108,7 @@ struct RayQueue {
     float* energy;           // RayWithEnergy::energy
     float* weight;           // product of blend factors from the primary ray down to this ray
     uint32_t* pixel;         // index into the (tile-compact) output buffer
+    uint32_t* depth;         // trace depth of the ray (for max_depth and the hard cap)
     unsigned long long* key; // RNG path key
 };
 
@@ -138,6 +141,7 @@ struct DRender {
     uint32_t max_depth;
     uint32_t band_rows, band_owner, band_owners;
     uint32_t first_batch;        // 1: store into out, 0: add
+    uint32_t use_rng;            // 0 when no random number can be consumed (window == 0, no area light)
     double window_width;
     double eye[3];
     double m[16];                // (P V)^-1 column-major

@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -25,34 +26,53 @@
 
 namespace nrays {
 
+#ifndef NRAYS_WAVES_PER_SIMD
+#define NRAYS_WAVES_PER_SIMD 2 // second __launch_bounds__ argument: caps the VGPR budget at 512 / this
+#endif
 constexpr int kTile = 16;          // a workgroup renders a 16x16 pixel tile
-constexpr int kChunkTiles = 32;    // consecutive tiles given to one XCD before moving to the next
 constexpr int kMaxGrid = 2048;     // persistent grid: 256 CUs x 8 workgroups
 constexpr int kSpillDepth = 96;    // HBM spill entries per lane (only allocated for very deep trees)
 
-// Persistent-grid work index -> tile index.  Workgroup b is observed to run on XCD b % 8; chunks of
-// kChunkTiles consecutive tiles are dealt to XCDs round-robin so that each XCD's private L2 keeps
-// seeing the same region of the BVH while the image is still covered evenly (speed only — any
-// placement gives the same pixels).
-__device__ __forceinline__ uint32_t work_to_tile(uint32_t w) {
-    uint32_t xcd = w & 7u, j = w >> 3;
-    uint32_t chunk = j / kChunkTiles, within = j % kChunkTiles;
-    return (chunk * 8u + xcd) * kChunkTiles + within;
+// XCD-aware dynamic scheduling of the persistent grid.  The tiles (in row-major order) are cut into 8
+// contiguous ranges, one per XCD, each with its own work counter in HBM.  A workgroup reads the id
+// of the XCD it runs on and pulls tiles from that XCD's range — so one XCD's private 4 MiB L2 keeps
+// seeing the same region of the image and of the BVH — and when the range is exhausted it steals
+// from the next XCD's range, which removes the tail of a static split (ball / foliage pixels cost
+// 5-10x a sky pixel).  Placement only affects speed: any assignment yields the same pixels.
+__device__ __forceinline__ uint32_t xcc_id() {
+    uint32_t v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    return v & 7u;
+}
+// Per-WAVE dequeue of 8x8-pixel wave tiles: lane 0 pulls, the index is broadcast through an SGPR;
+// no workgroup barrier is involved, so a wave that drew cheap (sky) tiles never waits for a sibling
+// that drew expensive ones.  The atomic for the NEXT grab is issued before the current tiles are
+// traced, so its ~1 us latency hides behind the work.  Wave tiles are numbered so that four
+// consecutive ones form a 16x16 pixel block.
+// `grab` (wave tiles per atomic) is chosen per scene on the host: analytic-only scenes have ~5 us tiles
+// and are bound by atomic throughput (large, prefetched grabs); mesh scenes have tiles whose cost
+// varies 10x+ and are bound by the tail (one tile per grab, no reserve-ahead).
+__device__ __forceinline__ uint32_t issue_grab(uint32_t* work_counters, uint32_t victim, uint32_t grab) {
+    uint32_t k = 0;
+    if (__lane_id() == 0) k = atomicAdd(&work_counters[victim], grab);
+    return k; // valid in lane 0; consumed later through readfirstlane
 }
 
 __device__ __forceinline__ void flush_counters(DeviceCounters* ctr, const Cnt& c, bool stats) {
     // wave-level reduction, then one atomic per wave and class
-    unsigned sh = c.shadow, rl = c.refl, rf = c.refr;
+    unsigned sh = c.shadow, rl = c.refl, rf = c.refr, md = c.max_depth;
     unsigned nd = c.node, tr = c.tri, pr = c.prim, ht = c.hit, tx = c.tex;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         sh += __shfl_down(sh, off); rl += __shfl_down(rl, off); rf += __shfl_down(rf, off);
+        unsigned om = __shfl_down(md, off); md = om > md ? om : md;
         if (stats) { nd += __shfl_down(nd, off); tr += __shfl_down(tr, off); pr += __shfl_down(pr, off); ht += __shfl_down(ht, off); tx += __shfl_down(tx, off); }
     }
     if (__lane_id() == 0) {
         if (sh) atomicAdd(&ctr->rays_shadow, (unsigned long long)sh);
         if (rl) atomicAdd(&ctr->rays_reflection, (unsigned long long)rl);
         if (rf) atomicAdd(&ctr->rays_refraction, (unsigned long long)rf);
+        if (md) atomicMax(&ctr->max_depth, md);
         if (stats) {
             atomicAdd(&ctr->node_tests, (unsigned long long)nd); atomicAdd(&ctr->tri_tests, (unsigned long long)tr);
             atomicAdd(&ctr->prim_tests, (unsigned long long)pr); atomicAdd(&ctr->hit_records, (unsigned long long)ht);
@@ -61,25 +81,60 @@ __device__ __forceinline__ void flush_counters(DeviceCounters* ctr, const Cnt& c
     }
 }
 
-template <bool STATS>
-__global__ void __launch_bounds__(kBlock) k_primary(DScene S, DRender R, QueueOut qo, float* __restrict__ out, DeviceCounters* ctr,
-                                                     uint32_t* spill, uint32_t tiles_x, uint32_t tiles_y, uint32_t work_items) {
+// Waves per SIMD requested per permutation (measured on MI355X, tools/kbench.py): the opaque mesh
+// kernel is latency-bound and prefers 3 waves with a few spills; the others run best at 2 without.
+constexpr int waves_per_simd(int feat) { return feat == kFeatMesh ? (NRAYS_WAVES_PER_SIMD > 3 ? NRAYS_WAVES_PER_SIMD : 3) : NRAYS_WAVES_PER_SIMD; }
+
+template <bool STATS, int FEAT>
+__global__ void __launch_bounds__(kBlock, waves_per_simd(FEAT)) k_primary(DScene S, DRender R, QueueOut qo, float* __restrict__ out, DeviceCounters* ctr,
+                                                     uint32_t* spill, uint32_t tiles_x, uint32_t tiles_y, uint32_t* work_counters, uint32_t grab) {
     __shared__ uint32_t lds_stack[kLdsStack * kBlock];
     Stack st;
     st.lds = lds_stack + threadIdx.x;
     st.spill_stride = gridDim.x * kBlock;
     st.spill = spill ? spill + (size_t)blockIdx.x * kBlock + threadIdx.x : nullptr;
     st.sp = 0;
-    Cnt cnt; cnt.node = cnt.tri = cnt.prim = cnt.hit = cnt.tex = cnt.shadow = cnt.refl = cnt.refr = 0;
+    Cnt cnt; cnt.node = cnt.tri = cnt.prim = cnt.hit = cnt.tex = cnt.shadow = cnt.refl = cnt.refr = cnt.max_depth = 0;
 
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint32_t lx = ((wave & 1u) << 3) | (lane & 7u), ly = ((wave >> 1) << 3) | (lane >> 3);
-    const uint32_t ntiles = tiles_x * tiles_y;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t nwt = tiles_x * tiles_y * 4u; // wave tiles: 4 per 16x16 block
 
-    for (uint32_t w = blockIdx.x; w < work_items; w += gridDim.x) {
-        uint32_t tile = work_to_tile(w);
-        if (tile >= ntiles) continue; // block-uniform
+    // grab == 0: static assignment, wave tiles interleaved over all resident waves (no atomics): expensive
+    // regions are spread evenly, which is what cheap analytic scenes want.  grab >= 1: dynamic.
+    const uint32_t total_waves = gridDim.x * (kBlock / 64), my_wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    uint32_t victim = xcc_id();
+    const uint32_t g = grab ? grab : 1u;
+    const uint32_t per = (((nwt + 7u) / 8u) + g - 1u) / g * g; // wave tiles per XCD range
+    const bool prefetch = grab > 1u;
+    uint32_t pending = grab ? issue_grab(work_counters, victim, grab) : 0u;
+    uint32_t static_next = my_wave;
+    for (;;) {
+      uint32_t first, last;
+      if (grab == 0u) {
+          if (static_next >= nwt) break;
+          first = static_next; last = first + 1u; static_next += total_waves;
+      } else {
+          uint32_t k = (uint32_t)__builtin_amdgcn_readfirstlane((int)pending);
+          uint32_t begin = victim * per, end = begin + per < nwt ? begin + per : nwt;
+          first = begin + k;
+          if (begin >= end || first >= end) { // this XCD's range is exhausted: steal from the next non-empty one
+              bool found = false;
+              for (uint32_t tries = 0; tries < 7u && !found; ++tries) {
+                  victim = (victim + 1u) & 7u;
+                  begin = victim * per; end = begin + per < nwt ? begin + per : nwt;
+                  if (begin >= end) continue;
+                  k = (uint32_t)__builtin_amdgcn_readfirstlane((int)issue_grab(work_counters, victim, grab));
+                  if (begin + k < end) { first = begin + k; found = true; }
+              }
+              if (!found) break; // wave-uniform
+          }
+          last = first + grab < end ? first + grab : end;
+          if (prefetch) pending = issue_grab(work_counters, victim, grab); // issued now, consumed after the tiles below
+      }
+      for (uint32_t wt = first; wt < last; ++wt) {
+        uint32_t tile = wt >> 2, sub = wt & 3u;
         uint32_t tx = tile % tiles_x, ty = tile / tiles_x;
+        uint32_t lx = ((sub & 1u) << 3) | (lane & 7u), ly = ((sub >> 1) << 3) | (lane >> 3);
         uint32_t i = tx * kTile + lx, rl = ty * kTile + ly; // column, local (compact) row
         // local row -> global row (framebuffer bands dealt round-robin to owners)
         uint32_t j = rl;
@@ -93,7 +148,7 @@ __global__ void __launch_bounds__(kBlock) k_primary(DScene S, DRender R, QueueOu
         for (uint32_t s = R.sample_begin; s < R.sample_end; ++s) {
             RayState ray;
             generate_primary(R, i, j, s, pix, ray);
-            f3 c = shade_and_continue<STATS>(S, st, active, ray, 0u, R.max_depth, qo, cnt);
+            f3 c = trace_chain<STATS, FEAT>(S, st, active, ray, 0u, R.max_depth, qo, cnt);
             tot.x = tot.x + c.x; tot.y = tot.y + c.y; tot.z = tot.z + c.z;
         }
         if (active) {
@@ -104,21 +159,23 @@ __global__ void __launch_bounds__(kBlock) k_primary(DScene S, DRender R, QueueOu
             float* o = out + (size_t)pix * 3;
             o[0] = 0.0f; o[1] = 0.0f; o[2] = 0.0f;
         }
+      }
+      if (grab == 1u) pending = issue_grab(work_counters, victim, grab);
     }
     flush_counters(ctr, cnt, STATS);
 }
 
 template <bool STATS>
-__global__ void __launch_bounds__(kBlock) k_bounce(DScene S, RayQueue qin, const uint32_t* __restrict__ count_in, uint32_t capacity,
+__global__ void __launch_bounds__(kBlock, NRAYS_WAVES_PER_SIMD) k_bounce(DScene S, RayQueue qin, const uint32_t* __restrict__ count_in, uint32_t capacity,
                                                     QueueOut qo, float* __restrict__ out, DeviceCounters* ctr, uint32_t* spill,
-                                                    uint32_t depth, uint32_t max_depth) {
+                                                    uint32_t max_depth) {
     __shared__ uint32_t lds_stack[kLdsStack * kBlock];
     Stack st;
     st.lds = lds_stack + threadIdx.x;
     st.spill_stride = gridDim.x * kBlock;
     st.spill = spill ? spill + (size_t)blockIdx.x * kBlock + threadIdx.x : nullptr;
     st.sp = 0;
-    Cnt cnt; cnt.node = cnt.tri = cnt.prim = cnt.hit = cnt.tex = cnt.shadow = cnt.refl = cnt.refr = 0;
+    Cnt cnt; cnt.node = cnt.tri = cnt.prim = cnt.hit = cnt.tex = cnt.shadow = cnt.refl = cnt.refr = cnt.max_depth = 0;
     uint32_t n = *count_in;
     if (n > capacity) n = capacity;
     for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) { // block-uniform trip count
@@ -126,8 +183,9 @@ __global__ void __launch_bounds__(kBlock) k_bounce(DScene S, RayQueue qin, const
         bool active = idx < n;
         RayState ray;
         ray.o = D3(0, 0, 0); ray.d = D3(0, 0, 1); ray.refr = 1.0; ray.energy = 0.0f; ray.weight = 0.0f; ray.key = 0; ray.pixel = 0;
-        if (active) queue_load(qin, idx, ray);
-        f3 c = shade_and_continue<STATS>(S, st, active, ray, depth, max_depth, qo, cnt);
+        uint32_t depth = 0;
+        if (active) queue_load(qin, idx, ray, depth);
+        f3 c = trace_chain<STATS, kFeatAll>(S, st, active, ray, depth, max_depth, qo, cnt);
         if (active) {
             float* o = out + (size_t)ray.pixel * 3;
             unsafeAtomicAdd(o, c.x); unsafeAtomicAdd(o + 1, c.y); unsafeAtomicAdd(o + 2, c.z);
@@ -189,6 +247,7 @@ struct NraysScene {
     DeviceCounters* d_counters = nullptr;
     uint32_t* d_spill = nullptr;
     bool need_spill = false;
+    int features = kFeatAll;
     float* d_frame = nullptr; size_t frame_floats = 0;
     hipStream_t own_stream = nullptr;
     // ring of HIP event triples (frame begin, primary kernel begin/end, frame end) recorded on the render
@@ -201,7 +260,6 @@ struct NraysScene {
     bool have_last = false;
     NraysStats last;
     uint64_t last_primary = 0, last_primary_first_batch = 0;
-    uint32_t last_generations = 0;
     bool last_instrumented = false;
 };
 
@@ -224,7 +282,7 @@ static int ensure_queue(NraysScene* sc, uint32_t capacity) {
     for (int k = 0; k < 2; ++k) {
         if (sc->queue[k].block) { (void)hipFree(sc->queue[k].block); sc->queue[k].block = nullptr; }
         size_t cap = capacity;
-        size_t bytes = cap * (8 * 7 + 4 * 3 + 8);
+        size_t bytes = cap * (8 * 7 + 4 * 4 + 8);
         void* p = nullptr;
         HIP_TRY(hipMalloc(&p, bytes));
         sc->queue[k].block = p;
@@ -237,6 +295,7 @@ static int ensure_queue(NraysScene* sc, uint32_t capacity) {
         q.energy = (float*)c; c += cap * 4;
         q.weight = (float*)c; c += cap * 4;
         q.pixel = (uint32_t*)c; c += cap * 4;
+        q.depth = (uint32_t*)c; c += cap * 4;
     }
     sc->queue_capacity = capacity;
     return NRAYS_OK;
@@ -246,6 +305,23 @@ static uint32_t tile_rows(const NraysRenderParams* p) {
     if (p->band_rows == 0 || p->band_owners <= 1) return p->height;
     uint32_t nb = (p->height + p->band_rows - 1) / p->band_rows;
     return ((nb + p->band_owners - 1) / p->band_owners) * p->band_rows;
+}
+
+// The primary kernel is instantiated per feature set; instrumented renders and k_bounce use the
+// full-featured code (their results are identical, only slower).
+static void launch_primary(bool instrumented, int features, uint32_t grid, hipStream_t stream, const DScene& d, const DRender& R,
+                           const QueueOut& qo, float* out, DeviceCounters* ctr, uint32_t* spill, uint32_t tx, uint32_t ty, uint32_t* work, uint32_t grab) {
+#define NR_LAUNCH(F) hipLaunchKernelGGL((k_primary<false, F>), dim3(grid), dim3(kBlock), 0, stream, d, R, qo, out, ctr, spill, tx, ty, work, grab)
+    if (instrumented) { hipLaunchKernelGGL((k_primary<true, kFeatAll>), dim3(grid), dim3(kBlock), 0, stream, d, R, qo, out, ctr, spill, tx, ty, work, grab); return; }
+    switch (features) {
+    case 1: NR_LAUNCH(1); break;
+    case 2: NR_LAUNCH(2); break;
+    case 3: NR_LAUNCH(3); break;
+    case 5: NR_LAUNCH(5); break;
+    case 6: NR_LAUNCH(6); break;
+    default: NR_LAUNCH(7); break;
+    }
+#undef NR_LAUNCH
 }
 
 static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out, hipStream_t stream, bool instrumented) {
@@ -263,8 +339,10 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
     const uint64_t kMaxPrimaryPerLaunch = 32ull << 20;
     uint32_t batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(p->ray_per_pixel, kMaxPrimaryPerLaunch / std::max<uint64_t>(1, npix_local)));
 
-    const bool continuations = sc->host.any_reflective || sc->host.any_transparent;
-    if (continuations) {
+    // Continuation rays stay in registers (trace_chain); the HBM queue is only needed when one hit can
+    // spawn both a reflection and a refraction.
+    const bool queued = sc->host.any_double_branch;
+    if (queued) {
         uint64_t want = std::min<uint64_t>(std::max<uint64_t>(4 * npix_local * batch, 1u << 16), 1ull << 27);
         int rc = ensure_queue(sc, (uint32_t)want);
         if (rc != NRAYS_OK) return rc;
@@ -284,58 +362,43 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
 
     const uint32_t tiles_x = (p->width + kTile - 1) / kTile, tiles_y = (rows + kTile - 1) / kTile;
     const uint32_t ntiles = tiles_x * tiles_y;
-    const uint32_t group = 8u * kChunkTiles;
-    const uint32_t work_items = ((ntiles + group - 1) / group) * group;
-    const uint32_t grid_primary = std::min<uint32_t>(work_items, kMaxGrid);
-
-    // generation budget: energy rule bound for reflection-only scenes, host-controlled otherwise
-    uint32_t gen_cap = kMaxGenerations;
-    if (p->max_depth != 0) gen_cap = std::min<uint32_t>(gen_cap, p->max_depth);
-    uint32_t gens_static = 0;
-    bool host_controlled = false;
-    if (continuations) {
-        if (sc->host.any_transparent) host_controlled = true;
-        else gens_static = std::min<uint32_t>(sc->host.reflection_generations, gen_cap);
-    }
+    uint32_t grab = (sc->features & kFeatMesh) ? 1u : 0u; // 0 = static wave-interleaved assignment
+    if (const char* e = getenv("NRAYS_GRAB")) grab = (uint32_t)std::max(0, atoi(e)); // tuning override (tools/kbench.py)
+    const uint32_t grid_primary = std::min<uint32_t>(((ntiles + 7u) / 8u) * 8u, 256u * (uint32_t)waves_per_simd(instrumented ? kFeatAll : sc->features));
 
     const int slot = (int)(sc->frames_recorded % NraysScene::kRing);
     HIP_TRY(hipEventRecord(sc->ev_begin[slot], stream));
     HIP_TRY(hipMemsetAsync(sc->d_counters, 0, sizeof(DeviceCounters), stream));
-    uint32_t generations_run = 0;
+    R.use_rng = (p->window_width != 0.0 || sc->host.any_area_light) ? 1u : 0u;
     bool first_primary = true;
     for (uint32_t s0 = 0; s0 < p->ray_per_pixel; s0 += batch) {
         R.sample_begin = s0; R.sample_end = std::min<uint32_t>(p->ray_per_pixel, s0 + batch);
         R.first_batch = s0 == 0 ? 1u : 0u;
-        if (continuations) HIP_TRY(hipMemsetAsync(sc->d_counts, 0, (kMaxGenerations + 2) * sizeof(uint32_t), stream));
-        QueueOut qo; qo.q = sc->queue[1].q; qo.capacity = continuations ? sc->queue_capacity : 0; qo.count = sc->d_counts + 1;
+        // zeroes the queue counters and the 8 per-XCD work counters that follow them
+        HIP_TRY(hipMemsetAsync(sc->d_counts, 0, (kMaxGenerations + 2 + 8) * sizeof(uint32_t), stream));
+        QueueOut qo; qo.q = sc->queue[1].q; qo.capacity = queued ? sc->queue_capacity : 0; qo.count = sc->d_counts + 1;
         qo.overflow = &sc->d_counters->overflow;
         if (first_primary) HIP_TRY(hipEventRecord(sc->ev_pbegin[slot], stream));
-        if (instrumented) hipLaunchKernelGGL(k_primary<true>, dim3(grid_primary), dim3(kBlock), 0, stream, sc->d, R, qo, d_out, sc->d_counters, sc->d_spill, tiles_x, tiles_y, work_items);
-        else hipLaunchKernelGGL(k_primary<false>, dim3(grid_primary), dim3(kBlock), 0, stream, sc->d, R, qo, d_out, sc->d_counters, sc->d_spill, tiles_x, tiles_y, work_items);
+        launch_primary(instrumented, sc->features, grid_primary, stream, sc->d, R, qo, d_out, sc->d_counters, sc->d_spill, tiles_x, tiles_y, sc->d_counts + kMaxGenerations + 2, grab);
         HIP_TRY(hipGetLastError());
         if (first_primary) {
             HIP_TRY(hipEventRecord(sc->ev_pend[slot], stream));
             if (instrumented) HIP_TRY(hipMemcpyAsync(sc->d_counters_primary, sc->d_counters, sizeof(DeviceCounters), hipMemcpyDeviceToDevice, stream));
             first_primary = false;
         }
-
-        uint32_t gmax = host_controlled ? gen_cap : gens_static;
-        for (uint32_t g = 1; g <= gmax; ++g) {
-            uint32_t launch_n = sc->queue_capacity;
-            if (host_controlled) {
-                uint32_t n = 0;
-                HIP_TRY(hipMemcpyAsync(&n, sc->d_counts + g, sizeof n, hipMemcpyDeviceToHost, stream));
-                HIP_TRY(hipStreamSynchronize(stream));
-                if (n == 0) break;
-                launch_n = std::min<uint32_t>(n, sc->queue_capacity);
-            }
+        // rounds of queued second children (host-controlled: the count is read back after every round)
+        for (uint32_t r = 1; queued && r <= (uint32_t)kMaxGenerations; ++r) {
+            uint32_t n = 0;
+            HIP_TRY(hipMemcpyAsync(&n, sc->d_counts + r, sizeof n, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+            if (n == 0) break;
+            uint32_t launch_n = std::min<uint32_t>(n, sc->queue_capacity);
             uint32_t grid = std::min<uint32_t>((launch_n + kBlock - 1) / kBlock, kMaxGrid);
-            QueueOut qn; qn.q = sc->queue[(g + 1) & 1].q; qn.capacity = sc->queue_capacity; qn.count = sc->d_counts + g + 1;
+            QueueOut qn; qn.q = sc->queue[(r + 1) & 1].q; qn.capacity = sc->queue_capacity; qn.count = sc->d_counts + r + 1;
             qn.overflow = &sc->d_counters->overflow;
-            if (instrumented) hipLaunchKernelGGL(k_bounce<true>, dim3(grid), dim3(kBlock), 0, stream, sc->d, sc->queue[g & 1].q, sc->d_counts + g, sc->queue_capacity, qn, d_out, sc->d_counters, sc->d_spill, g, p->max_depth);
-            else hipLaunchKernelGGL(k_bounce<false>, dim3(grid), dim3(kBlock), 0, stream, sc->d, sc->queue[g & 1].q, sc->d_counts + g, sc->queue_capacity, qn, d_out, sc->d_counters, sc->d_spill, g, p->max_depth);
+            if (instrumented) hipLaunchKernelGGL(k_bounce<true>, dim3(grid), dim3(kBlock), 0, stream, sc->d, sc->queue[r & 1].q, sc->d_counts + r, sc->queue_capacity, qn, d_out, sc->d_counters, sc->d_spill, p->max_depth);
+            else hipLaunchKernelGGL(k_bounce<false>, dim3(grid), dim3(kBlock), 0, stream, sc->d, sc->queue[r & 1].q, sc->d_counts + r, sc->queue_capacity, qn, d_out, sc->d_counters, sc->d_spill, p->max_depth);
             HIP_TRY(hipGetLastError());
-            generations_run = std::max(generations_run, g);
         }
     }
     if (p->ray_per_pixel > 1) {
@@ -352,7 +415,6 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
     else for (uint32_t j = 0; j < p->height; ++j) if (((j / p->band_rows) % p->band_owners) == p->band_owner) ++owned_rows;
     sc->last_primary = owned_rows * p->width * p->ray_per_pixel;
     sc->last_primary_first_batch = owned_rows * p->width * std::min<uint32_t>(batch, p->ray_per_pixel);
-    sc->last_generations = generations_run;
     sc->last_instrumented = instrumented;
     return NRAYS_OK;
 }
@@ -405,14 +467,15 @@ int nrays_scene_create(const NraysSceneDesc* desc, NraysScene** out_scene) {
     for (int a = 0; a < 3; ++a) sc->d.background[a] = h.background[a];
     // stack bound: one deferred sibling per level of TLAS and BLAS, plus the sentinel
     sc->need_spill = (2 * h.max_bvh_depth + 4) > kLdsStack;
+    sc->features = h.features ? h.features : kFeatAll;
     // release bulk host copies
     std::vector<BvhNode>().swap(h.nodes); std::vector<TriRec>().swap(h.tris); std::vector<TriUv>().swap(h.triuvs);
 
-    if (hipMalloc((void**)&sc->d_counts, (kMaxGenerations + 2) * sizeof(uint32_t)) != hipSuccess ||
+    if (hipMalloc((void**)&sc->d_counts, (kMaxGenerations + 2 + 8) * sizeof(uint32_t)) != hipSuccess ||
         hipMalloc((void**)&sc->d_counters, sizeof(DeviceCounters)) != hipSuccess ||
         hipMalloc((void**)&sc->d_counters_primary, sizeof(DeviceCounters)) != hipSuccess)
         return bail(fail(NRAYS_ERR_OOM, "counter allocation failed"));
-    if (hipMemset(sc->d_counts, 0, (kMaxGenerations + 2) * sizeof(uint32_t)) != hipSuccess ||
+    if (hipMemset(sc->d_counts, 0, (kMaxGenerations + 2 + 8) * sizeof(uint32_t)) != hipSuccess ||
         hipMemset(sc->d_counters, 0, sizeof(DeviceCounters)) != hipSuccess)
         return bail(fail(NRAYS_ERR_HIP, "counter memset failed"));
     if (hipStreamCreate(&sc->own_stream) != hipSuccess) return bail(fail(NRAYS_ERR_HIP, "stream creation failed"));
@@ -469,7 +532,7 @@ int nrays_get_stats(NraysScene* sc, NraysStats* out) {
     HIP_TRY(hipMemcpy(&c, sc->d_counters, sizeof c, hipMemcpyDeviceToHost));
     out->rays_primary = sc->last_primary;
     fill_counters(out, c);
-    out->generations = sc->last_generations; out->instrumented = sc->last_instrumented ? 1u : 0u;
+    out->generations = c.max_depth; out->instrumented = sc->last_instrumented ? 1u : 0u;
     // average the event timings of the frames recorded since the previous call (at most kRing)
     uint64_t first = sc->frames_reported;
     if (sc->frames_recorded - first > (uint64_t)NraysScene::kRing) first = sc->frames_recorded - NraysScene::kRing;

@@ -161,7 +161,10 @@ int append_blas(const NraysSceneDesc* d, const std::vector<uint32_t>& node_ids, 
     }
     for (int a = 0; a < 3; ++a) { blas.mn[a] = std::numeric_limits<float>::infinity(); blas.mx[a] = -std::numeric_limits<float>::infinity(); }
     for (const PrimBounds& b : pb) for (int a = 0; a < 3; ++a) { blas.mn[a] = std::min(blas.mn[a], b.mn[a]); blas.mx[a] = std::max(blas.mx[a], b.mx[a]); }
-    BuiltBvh bvh = build_bvh(pb, 4);
+#ifndef NR_MAX_LEAF
+#define NR_MAX_LEAF 8
+#endif
+    BuiltBvh bvh = build_bvh(pb, NR_MAX_LEAF);
     if (out.tris.size() + recs.size() >= (1u << 28)) { err = "too many triangles"; return NRAYS_ERR_UNSUPPORTED; }
     rebase_bvh(bvh, (int32_t)out.nodes.size(), (uint32_t)out.tris.size());
     out.max_bvh_depth = std::max(out.max_bvh_depth, bvh.max_depth);
@@ -196,6 +199,7 @@ int build_host_scene(const NraysSceneDesc* d, HostScene& out, std::string& err) 
         LightRec r;
         for (int a = 0; a < 3; ++a) { r.pos[a] = l.pos[a]; r.color[a] = l.color[a]; }
         r.radius = l.radius; r.racsample = l.racsample;
+        if (l.radius != 0.0) out.any_area_light = true;
         out.lights.push_back(r);
     }
     for (uint32_t i = 0; i < d->num_textures; ++i) {
@@ -240,6 +244,7 @@ int build_host_scene(const NraysSceneDesc* d, HostScene& out, std::string& err) 
                         (m.kind == NRAYS_MAT_PHONG && (m.alpha_texture_id < 0 || !has_uv));
         info[i].opaque = w_is_one && n.alpha >= 1.0f;
         if (!(w_is_one && n.alpha == 1.0f)) out.any_transparent = true;
+        if (!(w_is_one && n.alpha == 1.0f) && n.refl_mix != 0.0f) out.any_double_branch = true;
         if (n.refl_mix != 0.0f) { out.any_reflective = true; att_min = std::min(att_min, n.refl_atenuation); }
         NodeRec r;
         r.refl_mix = n.refl_mix; r.refl_atenuation = n.refl_atenuation; r.alpha = n.alpha; r.material_id = n.material_id;
@@ -346,6 +351,16 @@ int build_host_scene(const NraysSceneDesc* d, HostScene& out, std::string& err) 
         }
     }
 
+    {   // kernel permutation: 1 = analytic shapes, 2 = meshes, 4 = some node may be non-opaque to shadow rays
+        int f = 0;
+        for (uint32_t i = 0; i < d->num_nodes; ++i) {
+            const NraysNode& n = d->nodes[i];
+            if (n.shape_kind == NRAYS_SHAPE_TRIMESH) { if (d->meshes[n.mesh_id].num_triangles) f |= 2; } else f |= 1;
+            if (!info[i].opaque) f |= 4;
+        }
+        if (f == 4 || f == 0) f |= 1; // empty scenes take the lightest kernel
+        out.features = f;
+    }
     out.closest_root = append_tlas(cinst, cbox, out);
     out.shadow_root = append_tlas(sinst, sbox, out);
     for (size_t k = 0; k < planes_c.size(); ++k) {

@@ -32,6 +32,15 @@ constexpr int32_t kSentinel = (int32_t)0x80000001; // marks "leave the BLAS" on 
 
 #define NR_DEV __device__ __forceinline__
 
+// Kernel permutations by scene content (decided once per scene on the host): a scene only pays, in
+// registers and instructions, for the code paths it can reach.
+enum Features : int {
+    kFeatAnalytic = 1,     // balls / cuboids / cylinders / capsules / cones / planes exist
+    kFeatMesh = 2,         // TriMesh nodes exist (BLAS traversal, ray/triangle)
+    kFeatAlphaShadow = 4,  // some node may be non-opaque to shadow rays (per-node closest hit + colour filter)
+    kFeatAll = 7
+};
+
 // ---------------------------------------------------------------- vector algebra (f64) -------
 struct d3 { double x, y, z; };
 NR_DEV d3 D3(double x, double y, double z) { d3 r; r.x = x; r.y = y; r.z = z; return r; }
@@ -69,6 +78,7 @@ constexpr unsigned long long kSaltPath = 2ULL, kSaltRefl = 0x100ULL, kSaltRefr =
 struct Cnt {
     unsigned node, tri, prim, hit, tex;     // instrumented builds only
     unsigned shadow, refl, refr;            // ray classes, always counted
+    unsigned max_depth;                     // deepest trace depth reached by this lane
 };
 
 // ---------------------------------------------------------------- traversal stack ------------
@@ -548,14 +558,15 @@ NR_DEV bool tri_aabb_pass(d3 a, d3 b, d3 c, d3 o, d3 d) {
 }
 
 // Reconstructs the full intersection record of a finished closest-hit query.
-template <bool SHADOW>
+template <bool SHADOW, int FEAT>
 NR_DEV void resolve_hit(const DScene& S, d3 o, d3 d, const Hit& h, Isect& out, uint32_t& node_id) {
     const Instance& in = (SHADOW ? S.shadow_instances : S.instances)[h.inst];
-    if (in.kind != NRAYS_SHAPE_TRIMESH) {
+    if ((FEAT & kFeatAnalytic) && (!(FEAT & kFeatMesh) || in.kind != NRAYS_SHAPE_TRIMESH)) {
         cast_analytic(in, o, d, out);
         node_id = (uint32_t)in.node_id;
         return;
     }
+    if (!(FEAT & kFeatMesh)) { node_id = 0; out.toi = 0.0; out.n = D3(0, 0, 0); out.u = out.v = 0.0; out.has_uv = false; return; }
     Xform m; load_xform(in, m);
     d3 lo = o, ld = d;
     if (!(in.flags & kInstIdentityRot)) { lo = inv_rot(m, o - m.t); ld = inv_rot(m, d); }
@@ -598,8 +609,10 @@ NR_DEV bool shadow_node_hit(const DScene& S, uint32_t node_id, const Isect& is, 
 //   SHADOW == true : TransparentShadowsRayTOICostFn — returns true if an opaque node-closest hit
 //                    lies within `tlimit`; otherwise `filter` holds the product of the transparent
 //                    node-closest hits' colour filters.
-template <bool SHADOW, bool STATS>
+template <bool SHADOW, bool STATS, int FEAT>
 NR_DEV bool traverse(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, Hit& hit, f3& filter, Cnt& cnt) {
+    constexpr bool kAnalytic = (FEAT & kFeatAnalytic) != 0, kMesh = (FEAT & kFeatMesh) != 0;
+    constexpr bool kAlpha = (FEAT & kFeatAlphaShadow) != 0; // shadow mode: otherwise every hit within tlimit blocks
     const Instance* insts = SHADOW ? S.shadow_instances : S.instances;
     double bt = SHADOW ? tlimit : kDblMax;
     unsigned long long bkey = ~0ULL;
@@ -614,7 +627,7 @@ NR_DEV bool traverse(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, Hit&
     st.sp = 0;
     // planes have infinite AABBs (ncollide Plane AABB = +-MAX): kept out of the BVH and visited as
     // pseudo-leaves, pushed first so that they are tested after the TLAS has tightened the bound.
-    {
+    if (kAnalytic) {
         const int32_t* planes = SHADOW ? S.shadow_planes : S.planes;
         for (uint32_t p = 0; p < S.num_planes; ++p) st.push(~(int32_t)(((uint32_t)planes[p]) << 3));
     }
@@ -624,14 +637,14 @@ NR_DEV bool traverse(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, Hit&
         if (cur == kEmptyChild) {
             if (st.sp == 0) break;
             cur = st.pop();
-            if (cur == kSentinel) { // the BLAS of `cur_inst` is exhausted: back to world space
+            if (kMesh && cur == kSentinel) { // the BLAS of `cur_inst` is exhausted: back to world space
                 in_blas = false;
                 co = o; cd = d; rf = make_rayf(o, d);
-                if (SHADOW && !(cur_flags & kInstAnyHit)) {
+                if (SHADOW && kAlpha && !(cur_flags & kInstAnyHit)) {
                     if (bhit) {
                         Hit h; h.t = bt; h.inst = cur_inst; h.prim = bprim;
                         Isect is; uint32_t node_id;
-                        resolve_hit<true>(S, o, d, h, is, node_id);
+                        resolve_hit<true, FEAT>(S, o, d, h, is, node_id);
                         if (shadow_node_hit<STATS>(S, node_id, is, filter, cnt)) return true;
                     }
                     bt = tlimit; bkey = ~0ULL; bhit = false; btf = best_f32(bt);
@@ -657,9 +670,9 @@ NR_DEV bool traverse(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, Hit&
         // leaf
         uint32_t lv = (uint32_t)~cur;
         uint32_t first = lv >> 3, count = (lv & 7u) + 1u;
-        if (!in_blas) { // TLAS leaf = one instance
+        if (!kMesh || !in_blas) { // TLAS leaf = one instance
             const Instance& in = insts[first];
-            if (in.kind == NRAYS_SHAPE_TRIMESH) {
+            if (kMesh && (!kAnalytic || in.kind == NRAYS_SHAPE_TRIMESH)) {
                 cur_inst = first; cur_flags = in.flags;
                 Xform m; load_xform(in, m);
                 if (in.flags & kInstIdentityRot) { co = o - m.t; cd = d; }
@@ -670,11 +683,15 @@ NR_DEV bool traverse(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, Hit&
                 cur = in.blas_root;
                 continue;
             }
+            if (!kAnalytic) { cur = kEmptyChild; continue; }
             if (STATS) cnt.prim++;
             Isect is;
             if (cast_analytic(in, o, d, is) && (in.kind == NRAYS_SHAPE_PLANE || node_aabb_pass(S, (uint32_t)in.node_id, o, d))) {
                 if (SHADOW) {
-                    if (is.toi <= tlimit && shadow_node_hit<STATS>(S, (uint32_t)in.node_id, is, filter, cnt)) return true;
+                    if (is.toi <= tlimit) {
+                        if (!kAlpha) return true;
+                        if (shadow_node_hit<STATS>(S, (uint32_t)in.node_id, is, filter, cnt)) return true;
+                    }
                 } else {
                     unsigned long long key = (unsigned long long)(uint32_t)in.node_id << 32;
                     if (is.toi < bt || (is.toi == bt && key < bkey)) { bt = is.toi; bkey = key; bhit = true; binst = first; bprim = 0; btf = best_f32(bt); }
@@ -684,6 +701,8 @@ NR_DEV bool traverse(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, Hit&
             continue;
         }
         // triangle leaf
+        if (!kMesh) { cur = kEmptyChild; continue; }
+#pragma nounroll
         for (uint32_t k = 0; k < count; ++k) {
             const float4* tq = (const float4*)(S.tris + first + k);
             float4 t0 = tq[0], t1 = tq[1], t2 = tq[2];
@@ -692,7 +711,7 @@ NR_DEV bool traverse(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, Hit&
             d3 va = D3(t0.x, t0.y, t0.z), vb = D3(t1.x, t1.y, t1.z), vc = D3(t2.x, t2.y, t2.z);
             if (cast_triangle(va, vb, vc, co, cd, toi, nullptr, nullptr) && tri_aabb_pass(va, vb, vc, co, cd) &&
                 node_aabb_pass(S, __float_as_uint(t0.w), o, d)) {
-                if (SHADOW && (cur_flags & kInstAnyHit)) { if (toi <= tlimit) return true; }
+                if (SHADOW && (!kAlpha || (cur_flags & kInstAnyHit))) { if (toi <= tlimit) return true; }
                 else {
                     unsigned long long key = SHADOW ? (unsigned long long)__float_as_uint(t1.w)
                                                     : (((unsigned long long)__float_as_uint(t0.w) << 32) | __float_as_uint(t1.w));
@@ -719,8 +738,26 @@ struct RayState { // RayWithEnergy (ray_with_energy.rs:4-8) + bookkeeping of the
 };
 
 // PhongMaterial::compute (phong_material.rs:72-151); other materials fall back to ambiant (material.rs:8-16).
-template <bool STATS>
-NR_DEV f4 material_compute(const DScene& S, Stack& st, const MaterialRec& m, const RayState& ray, d3 point, const Isect& in, Cnt& cnt) {
+#ifdef NR_MAT_NOINLINE
+#define NR_MAT_ATTR __device__ __noinline__
+#else
+#define NR_MAT_ATTR NR_DEV
+#endif
+#ifdef NR_SHADOW_NOINLINE
+template <bool STATS, int FEAT>
+__device__ __noinline__ bool shadow_query(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, f3& filter, Cnt& cnt) {
+    Hit dummy;
+    return traverse<true, STATS, FEAT>(S, st, o, d, tlimit, dummy, filter, cnt);
+}
+#else
+template <bool STATS, int FEAT>
+NR_DEV bool shadow_query(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, f3& filter, Cnt& cnt) {
+    Hit dummy;
+    return traverse<true, STATS, FEAT>(S, st, o, d, tlimit, dummy, filter, cnt);
+}
+#endif
+template <bool STATS, int FEAT>
+NR_MAT_ATTR f4 material_compute(const DScene& S, Stack& st, const MaterialRec& m, const RayState& ray, d3 point, const Isect& in, Cnt& cnt) {
     if (m.kind != NRAYS_MAT_PHONG) return material_ambiant<STATS>(S, m, in, cnt);
     f4 tex; tex.x = tex.y = tex.z = tex.w = 1.0f;
     float alpha = 1.0f;
@@ -728,11 +765,13 @@ NR_DEV f4 material_compute(const DScene& S, Stack& st, const MaterialRec& m, con
     if (in.has_uv && m.alpha_tex >= 0) alpha = tex_sample<STATS>(S.textures[m.alpha_tex], in.u, in.v, cnt).w;
     f3 res = F3(m.ka[0] * tex.x, m.ka[1] * tex.y, m.ka[2] * tex.z);
     d3 normal = in.n;
+#pragma nounroll
     for (uint32_t li = 0; li < S.num_lights; ++li) {
         const LightRec& light = S.lights[li];
         f3 acc = F3(0.0f, 0.0f, 0.0f);
         uint32_t ns = light.racsample * light.racsample;
         unsigned long long lkey = rng_hash(ray.key, kSaltLight + li);
+#pragma nounroll
         for (uint32_t k = 0; k < ns; ++k) {
             d3 pos = D3(light.pos[0], light.pos[1], light.pos[2]);
             if (light.radius != 0.0) { // light.rs:59-61 (cube-octant jitter)
@@ -746,9 +785,8 @@ NR_DEV f4 material_compute(const DScene& S, Stack& st, const MaterialRec& m, con
             double dist = nrm - 0.001;
             d3 so = point + ldir * 0.001;
             f3 filter = F3(1.0f, 1.0f, 1.0f);
-            Hit dummy;
             cnt.shadow++;
-            if (traverse<true, STATS>(S, st, so, ldir, dist, dummy, filter, cnt)) continue; // shadowed
+            if (shadow_query<STATS, FEAT>(S, st, so, ldir, dist, filter, cnt)) continue; // shadowed
             double dot_ldir_norm = dot(ldir, normal);
             float dcoeff = (float)dot_ldir_norm;
             dcoeff = dcoeff > 0.0f ? dcoeff : 0.0f;
@@ -785,92 +823,110 @@ struct QueueOut {
     unsigned int* overflow;
 };
 
-NR_DEV void queue_store(const RayQueue& q, uint32_t i, const RayState& r) {
+NR_DEV void queue_store(const RayQueue& q, uint32_t i, const RayState& r, uint32_t depth) {
     q.o[0][i] = r.o.x; q.o[1][i] = r.o.y; q.o[2][i] = r.o.z;
     q.d[0][i] = r.d.x; q.d[1][i] = r.d.y; q.d[2][i] = r.d.z;
     q.refr[i] = r.refr; q.energy[i] = r.energy; q.weight[i] = r.weight; q.pixel[i] = r.pixel; q.key[i] = r.key;
+    q.depth[i] = depth;
 }
-NR_DEV void queue_load(const RayQueue& q, uint32_t i, RayState& r) {
+NR_DEV void queue_load(const RayQueue& q, uint32_t i, RayState& r, uint32_t& depth) {
     r.o = D3(q.o[0][i], q.o[1][i], q.o[2][i]);
     r.d = D3(q.d[0][i], q.d[1][i], q.d[2][i]);
     r.refr = q.refr[i]; r.energy = q.energy[i]; r.weight = q.weight[i]; r.pixel = q.pixel[i]; r.key = q.key[i];
+    depth = q.depth[i];
 }
 
-NR_DEV void emit_children(const QueueOut& qo, bool has_a, const RayState& a, bool has_b, const RayState& b) {
-    unsigned long long ma = __ballot(has_a), mb = __ballot(has_b);
-    uint32_t na = (uint32_t)__popcll(ma), nb = (uint32_t)__popcll(mb);
-    if (na + nb == 0) return; // wave-uniform
+// Appends the flagged lanes' rays to the continuation queue with ONE atomic per wave:
+// ballot -> popcount prefix -> base offset broadcast.  Must be reached by every lane of the wave.
+NR_DEV void emit_rays(const QueueOut& qo, bool has, const RayState& r, uint32_t depth) {
+    unsigned long long m = __ballot(has);
+    uint32_t n = (uint32_t)__popcll(m);
+    if (n == 0) return; // wave-uniform
     uint32_t lane = __lane_id();
+    int leader = __ffsll((long long)m) - 1;
     uint32_t base = 0;
-    if (lane == (uint32_t)(__ffsll((long long)(ma | mb)) - 1)) base = atomicAdd(qo.count, na + nb);
-    base = __shfl(base, __ffsll((long long)(ma | mb)) - 1);
-    unsigned long long lt = (1ULL << lane) - 1ULL;
-    if (has_a) {
-        uint32_t i = base + (uint32_t)__popcll(ma & lt);
-        if (i < qo.capacity) queue_store(qo.q, i, a); else atomicOr(qo.overflow, 1u);
-    }
-    if (has_b) {
-        uint32_t i = base + na + (uint32_t)__popcll(mb & lt);
-        if (i < qo.capacity) queue_store(qo.q, i, b); else atomicOr(qo.overflow, 1u);
+    if ((int)lane == leader) base = atomicAdd(qo.count, n);
+    base = __shfl(base, leader);
+    if (has) {
+        uint32_t i = base + (uint32_t)__popcll(m & ((1ULL << lane) - 1ULL));
+        if (i < qo.capacity) queue_store(qo.q, i, r, depth); else atomicOr(qo.overflow, 1u);
     }
 }
 
-// One step of the trace recursion unrolled (Scene::trace, scene.rs:163-193): closest hit, shade,
-// weight algebra, continuation rays.  Returns this ray's own weighted contribution to its pixel.
-// Must be called by every lane of the wave (inactive lanes pass active = false).
-template <bool STATS>
-NR_DEV f3 shade_and_continue(const DScene& S, Stack& st, bool active, const RayState& ray, uint32_t depth, uint32_t max_depth,
-                             const QueueOut& qo, Cnt& cnt) {
-    f3 contrib = F3(0.0f, 0.0f, 0.0f);
-    bool has_refl = false, has_refr = false;
-    RayState rr, rt;
-    rr = ray; rt = ray;
-    if (active) {
-        Hit hit; f3 nofilter = F3(1.0f, 1.0f, 1.0f);
-        if (!traverse<false, STATS>(S, st, ray.o, ray.d, kDblMax, hit, nofilter, cnt)) {
-            contrib = F3(S.background[0] * ray.weight, S.background[1] * ray.weight, S.background[2] * ray.weight);
-        } else {
-            Isect is; uint32_t node_id;
-            resolve_hit<false>(S, ray.o, ray.d, hit, is, node_id);
-            is.toi = hit.t;
-            if (STATS) cnt.hit++;
-            const NodeRec& sn = S.node_recs[node_id];
-            d3 pt = ray.o + ray.d * hit.t;
-            f4 obj = material_compute<STATS>(S, st, S.materials[sn.material_id], ray, pt, is, cnt);
-            bool may_recurse = depth < (uint32_t)kMaxGenerations && (max_depth == 0 || depth < max_depth);
-            float mix = sn.refl_mix;
-            float alpha = obj.w * sn.alpha;
-            float wa = alpha == 1.0f ? ray.weight : ray.weight * alpha; // scene.rs:183-190
-            // own term: obj.rgb * (1 - mix), scene.rs:179-180 (applied even when reflection is gated off)
-            float wo = wa * (1.0f - mix);
-            contrib = F3(obj.x * wo, obj.y * wo, obj.z * wo);
-            if (mix != 0.0f && ray.energy > 0.1f && may_recurse) { // trace_reflection, scene.rs:204-214
-                d3 nproj = is.n * dot(ray.d, is.n);
-                d3 rdir = ray.d - nproj * 2.0;
-                rr.o = pt + rdir * 0.001; rr.d = rdir; rr.refr = ray.refr; rr.energy = ray.energy - sn.refl_atenuation;
-                rr.weight = wa * mix; rr.key = rng_hash(ray.key, kSaltRefl); rr.pixel = ray.pixel;
-                has_refl = true; cnt.refl++;
-            }
-            if (alpha != 1.0f && may_recurse) { // trace_refraction, scene.rs:229-248
-                double n1, n2;
-                if (ray.refr == 1.0) { n1 = 1.0; n2 = sn.refr_coeff; } else { n1 = sn.refr_coeff; n2 = 1.0; }
-                d3 dir_along_normal = is.n * dot(ray.d, is.n);
-                d3 tangent = ray.d - dir_along_normal;
-                d3 new_dir = normalize(dir_along_normal + tangent * (n2 / n1));
-                rt.o = pt + new_dir * 0.001; rt.d = new_dir; rt.refr = n2; rt.energy = ray.energy;
-                rt.weight = ray.weight * (1.0f - alpha); rt.key = rng_hash(ray.key, kSaltRefr); rt.pixel = ray.pixel;
-                has_refr = true; cnt.refr++;
-            }
-        }
+// One step of the trace recursion (Scene::trace, scene.rs:163-193): closest hit, shade, weight
+// algebra.  Returns this ray's own weighted contribution to its pixel and its continuation rays.
+template <bool STATS, int FEAT>
+NR_DEV f3 shade_hit(const DScene& S, Stack& st, const RayState& ray, uint32_t depth, uint32_t max_depth,
+                    bool& has_refl, RayState& rr, bool& has_refr, RayState& rt, Cnt& cnt) {
+    has_refl = false; has_refr = false;
+    Hit hit; f3 nofilter = F3(1.0f, 1.0f, 1.0f);
+    if (!traverse<false, STATS, FEAT>(S, st, ray.o, ray.d, kDblMax, hit, nofilter, cnt))
+        return F3(S.background[0] * ray.weight, S.background[1] * ray.weight, S.background[2] * ray.weight);
+    Isect is; uint32_t node_id;
+    resolve_hit<false, FEAT>(S, ray.o, ray.d, hit, is, node_id);
+    is.toi = hit.t;
+    if (STATS) cnt.hit++;
+    const NodeRec& sn = S.node_recs[node_id];
+    d3 pt = ray.o + ray.d * hit.t;
+    f4 obj = material_compute<STATS, FEAT>(S, st, S.materials[sn.material_id], ray, pt, is, cnt);
+    bool may_recurse = depth < (uint32_t)kMaxGenerations && (max_depth == 0 || depth < max_depth);
+    float mix = sn.refl_mix;
+    float alpha = obj.w * sn.alpha;
+    float wa = alpha == 1.0f ? ray.weight : ray.weight * alpha; // scene.rs:183-190
+    // own term: obj.rgb * (1 - mix), scene.rs:179-180 (applied even when reflection is gated off)
+    float wo = wa * (1.0f - mix);
+    if (mix != 0.0f && ray.energy > 0.1f && may_recurse) { // trace_reflection, scene.rs:204-214
+        d3 nproj = is.n * dot(ray.d, is.n);
+        d3 rdir = ray.d - nproj * 2.0;
+        rr.o = pt + rdir * 0.001; rr.d = rdir; rr.refr = ray.refr; rr.energy = ray.energy - sn.refl_atenuation;
+        rr.weight = wa * mix; rr.key = rng_hash(ray.key, kSaltRefl); rr.pixel = ray.pixel;
+        has_refl = true; cnt.refl++;
     }
-    emit_children(qo, has_refl, rr, has_refr, rt);
-    return contrib;
+    if (alpha != 1.0f && may_recurse) { // trace_refraction, scene.rs:229-248
+        double n1, n2;
+        if (ray.refr == 1.0) { n1 = 1.0; n2 = sn.refr_coeff; } else { n1 = sn.refr_coeff; n2 = 1.0; }
+        d3 dir_along_normal = is.n * dot(ray.d, is.n);
+        d3 tangent = ray.d - dir_along_normal;
+        d3 new_dir = normalize(dir_along_normal + tangent * (n2 / n1));
+        rt.o = pt + new_dir * 0.001; rt.d = new_dir; rt.refr = n2; rt.energy = ray.energy;
+        rt.weight = ray.weight * (1.0f - alpha); rt.key = rng_hash(ray.key, kSaltRefr); rt.pixel = ray.pixel;
+        has_refr = true; cnt.refr++;
+    }
+    return F3(obj.x * wo, obj.y * wo, obj.z * wo);
+}
+
+// The recursion of Scene::trace unrolled into an iterative bounce loop.  A hit that spawns ONE
+// continuation (reflection or refraction: every shipped scene) keeps it in registers and loops;
+// when a hit spawns both, the refraction ray goes to the compacted HBM queue and is picked up by a
+// k_bounce launch.  Returns the sum of the chain's weighted contributions to ray.pixel.
+// Must be called by every lane of the wave (inactive lanes pass alive = false).
+template <bool STATS, int FEAT>
+NR_DEV f3 trace_chain(const DScene& S, Stack& st, bool alive, RayState ray, uint32_t depth, uint32_t max_depth,
+                      const QueueOut& qo, Cnt& cnt) {
+    f3 sum = F3(0.0f, 0.0f, 0.0f);
+    while (__ballot(alive) != 0ULL) { // wave-uniform
+        bool has_refl = false, has_refr = false;
+        RayState rr = ray, rt = ray;
+        if (alive) {
+            f3 c = shade_hit<STATS, FEAT>(S, st, ray, depth, max_depth, has_refl, rr, has_refr, rt, cnt);
+            sum.x = sum.x + c.x; sum.y = sum.y + c.y; sum.z = sum.z + c.z;
+            if (depth > cnt.max_depth) cnt.max_depth = depth;
+        }
+        if (qo.capacity != 0) emit_rays(qo, has_refl && has_refr, rt, depth + 1); // uniform: capacity is a kernel argument
+        if (has_refl) ray = rr; else if (has_refr) ray = rt;
+        alive = has_refl || has_refr;
+        ++depth;
+    }
+    return sum;
 }
 
 // scene.rs:74-89: jitter, NDC, unproject by (P V)^-1, normalise.
 NR_DEV void generate_primary(const DRender& R, uint32_t i, uint32_t j, uint32_t s, uint32_t pixel_out, RayState& ray) {
-    unsigned long long pkey = rng_hash(R.seed, (unsigned long long)i + (unsigned long long)j * R.width);
-    unsigned long long skey = rng_hash(pkey, s);
+    unsigned long long skey = 0;
+    if (R.use_rng) { // keys are only ever consumed by AA jitter and area-light sampling
+        unsigned long long pkey = rng_hash(R.seed, (unsigned long long)i + (unsigned long long)j * R.width);
+        skey = rng_hash(pkey, s);
+    }
     double ox = (double)i, oy = (double)j;
     if (R.window_width != 0.0) {
         ox = ox + (rng_u01(skey, 0) - 0.5) * R.window_width;
@@ -884,7 +940,7 @@ NR_DEV void generate_primary(const DRender& R, uint32_t i, uint32_t j, uint32_t 
     d3 eye = D3(h[0] / h[3], h[1] / h[3], h[2] / h[3]);
     d3 e0 = D3(R.eye[0], R.eye[1], R.eye[2]);
     ray.o = e0; ray.d = normalize(eye - e0); ray.refr = 1.0; ray.energy = 1.0f; ray.weight = 1.0f;
-    ray.key = rng_hash(skey, kSaltPath); ray.pixel = pixel_out;
+    ray.key = R.use_rng ? rng_hash(skey, kSaltPath) : 0ULL; ray.pixel = pixel_out;
 }
 
 } // namespace nrays
