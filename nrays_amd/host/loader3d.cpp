@@ -1,0 +1,75 @@
+// loader3d.cpp — the reference's CLI (examples/loader3d.rs:34-101) over the C ABI:
+//   loader3d <scene_file> [--width W --height H] [--spp N --window X] [--max-depth D] [--standins] [--ppm] [--cpu-threads N]
+// Loads the scene, creates the device scene once (nrays_scene_create), renders every camera with
+// nrays_render and writes the PNG named by the camera's `output`.  libnrays_hip.so is dlopen'ed so the
+// front-end itself builds without ROCm.
+#include <dlfcn.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "host.hpp"
+
+using namespace nrays_host;
+
+int main(int argc, char** argv) {
+    if (argc < 2) { std::fprintf(stderr, "Usage: %s scene_file [--width W --height H --spp N --window X --max-depth D --standins --ppm]\n", argv[0]); return 2; }
+    std::string path = argv[1];
+    long ow = 0, oh = 0, ospp = 0, maxd = 0; double owin = -1.0; bool standins = false, ppm = false;
+    for (int i = 2; i < argc; ++i) {
+        std::string a = argv[i];
+        auto val = [&]() -> const char* { if (i + 1 >= argc) { std::fprintf(stderr, "missing value for %s\n", a.c_str()); std::exit(2); } return argv[++i]; };
+        if (a == "--width") ow = std::atol(val()); else if (a == "--height") oh = std::atol(val());
+        else if (a == "--spp") ospp = std::atol(val()); else if (a == "--window") owin = std::atof(val());
+        else if (a == "--max-depth") maxd = std::atol(val()); else if (a == "--standins") standins = true; else if (a == "--ppm") ppm = true;
+        else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
+    }
+    try {
+        std::printf("Loading the scene.\n");
+        LoadOptions lo; lo.allow_standins = standins;
+        auto sc = load_scene_file(path, lo);
+        for (auto& w : sc->warnings) std::printf("%s\n", w.c_str());
+        std::printf("Scene loaded. %zu lights, %zu objects, %zu cameras.\n", sc->lights.size(), sc->nodes.size(), sc->cameras.size());
+
+        std::string self = argv[0]; size_t k = self.find_last_of('/');
+        std::string lib = (k == std::string::npos ? std::string(".") : self.substr(0, k)) + "/libnrays_hip.so";
+        void* h = dlopen(lib.c_str(), RTLD_NOW);
+        if (!h) h = dlopen("libnrays_hip.so", RTLD_NOW);
+        if (!h) { std::fprintf(stderr, "cannot load libnrays_hip.so: %s\n", dlerror()); return 1; }
+        auto create = (int (*)(const NraysSceneDesc*, NraysScene**))dlsym(h, "nrays_scene_create");
+        auto render = (int (*)(NraysScene*, const NraysRenderParams*, float*))dlsym(h, "nrays_render");
+        auto destroy = (void (*)(NraysScene*))dlsym(h, "nrays_scene_destroy");
+        auto last_error = (const char* (*)())dlsym(h, "nrays_last_error");
+        auto get_stats = (int (*)(NraysScene*, NraysStats*))dlsym(h, "nrays_get_stats");
+        if (!create || !render || !destroy || !last_error || !get_stats) { std::fprintf(stderr, "libnrays_hip.so lacks an ABI symbol\n"); return 1; }
+        NraysScene* scene = nullptr;
+        if (create(&sc->desc, &scene) != NRAYS_OK) { std::fprintf(stderr, "nrays_scene_create: %s\n", last_error()); return 1; }
+        for (const Camera& c : sc->cameras) {
+            NraysRenderParams p; std::memset(&p, 0, sizeof p);
+            p.width = (uint32_t)(ow ? ow : (long)c.resolution[0]); p.height = (uint32_t)(oh ? oh : (long)c.resolution[1]);
+            p.ray_per_pixel = (uint32_t)(ospp ? ospp : (long)c.aa[0]); p.window_width = owin >= 0 ? owin : c.aa[1];
+            p.max_depth = (uint32_t)maxd; p.band_owners = 1;
+            for (int a = 0; a < 3; ++a) p.camera_eye[a] = c.eye[a];
+            inverse_projection(c, (double)p.width, (double)p.height, p.inv_proj_view);
+            std::printf("Casting %u rays per pixels (win. %g).\n", p.ray_per_pixel, p.window_width);
+            std::printf("Tracing %llu rays.\n", (unsigned long long)p.width * p.height * p.ray_per_pixel);
+            std::vector<float> px((size_t)p.width * p.height * 3);
+            auto t0 = std::chrono::steady_clock::now();
+            if (render(scene, &p, px.data()) != NRAYS_OK) { std::fprintf(stderr, "nrays_render: %s\n", last_error()); return 1; }
+            double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            NraysStats st; get_stats(scene, &st);
+            unsigned long long rays = st.rays_primary + st.rays_reflection + st.rays_refraction + st.rays_shadow;
+            std::printf("Rays cast. %llu rays in %.3f ms (%.1f Mrays/s incl. the device-to-host copy; GPU %.3f ms)\n", rays, ms, rays / ms / 1e3, st.kernel_ms_total);
+            std::printf("Saving image to: %s\n", c.output.c_str());
+            if (ppm) write_ppm(c.output, px.data(), p.width, p.height);
+            else { auto q = quantize_rgb8(px.data(), px.size()); write_png_rgb8(c.output, q.data(), p.width, p.height); }
+            std::printf("Image saved.\n");
+        }
+        destroy(scene);
+    } catch (const std::exception& e) { std::fprintf(stderr, "%s\n", e.what()); return 1; }
+    return 0;
+}

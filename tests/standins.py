@@ -102,15 +102,18 @@ def _alpha_texture(kind, n=512):
     return nr.Texture2d(nr.ImageData(t), nr.Interpolation.Bilinear, nr.Overflow.Wrap)
 
 
-def sponza_scene(detail=1.0, n_lights=1):
-    """Atrium in OBJ units (x along the nave, y up), scaled by 1/4.  detail=1.0 gives ~262k triangles."""
-    global SPONZA_TRIS
+def sponza_geometry(detail=1.0):
+    """Atrium in OBJ units (x along the nave, y up; the loader scales by 1/4).  detail=1.0 gives ~262k
+    triangles.  Returns (points f32-exact in OBJ units, uvs, groups [(material name, faces)],
+    material definitions {name: (ka, kd, ks, tex name, alpha tex name, ns, d)}, textures {name: Texture2d})."""
     rng = np.random.default_rng(SPONZA_SEED)
     tex = {k: _procedural_texture(rng, k) for k in ("brick", "floor", "marble", "fabric", "leaf", "noise")}
-    lace, leaves = _alpha_texture("lace"), _alpha_texture("leaves")
+    tex["lace"], tex["leaves"] = _alpha_texture("lace"), _alpha_texture("leaves")
+    lace, leaves = "lace", "leaves"
+    tex_names = {id(v): k for k, v in tex.items()}
 
     def phong(ka, kd, ks, t=None, a=None, ns=60.0):
-        return nr.PhongMaterial(ka, kd, ks, t, a, ns)
+        return (ka, kd, ks, tex_names.get(id(t)) if t is not None and not isinstance(t, str) else t, a, ns)
     mats = {
         "floor": phong((.12, .12, .12), (1, 1, 1), (.3, .3, .3), tex["floor"]),
         "bricks": phong((.1, .1, .1), (1, 1, 1), (.1, .1, .1), tex["brick"]),
@@ -248,7 +251,21 @@ def sponza_scene(detail=1.0, n_lights=1):
         for k in range(6):
             quad("glass", (-L + 300 + k * 560.0, 500.0, s * (Wd - 4.0)), (240.0, 0, 0), (0, 300.0, 0), 2, 2, (1, 1))
 
-    pts, uvs, groups = mb.finish(0.25)
+    pts, uvs, groups = mb.finish(1.0)
+    defs = {k: v + (alphas.get(k, 1.0),) for k, v in mats.items()}
+    return pts, uvs, groups, defs, tex
+
+
+def sponza_scene(detail=1.0, n_lights=1):
+    """The stand-in as a Scene, built exactly as the loader would build it from the OBJ written by
+    tools/gen_assets.py: vertices / 4 (loader3d.rs:669), one SceneNode per group, node alpha = mtl d."""
+    global SPONZA_TRIS
+    pts, uvs, groups, defs, tex = sponza_geometry(detail)
+    pts = _f32(pts * 0.25)
+    mats = {}
+    for name, (ka, kd, ks, t, a, ns, d) in defs.items():
+        mats[name] = nr.PhongMaterial(ka, kd, ks, tex[t] if t else None, tex[a] if a else None, ns)
+    alphas = {name: v[6] for name, v in defs.items()}
     iso = nr.Isometry3((0.0, 0.0, 0.0), (0.0, 0.0, 0.0))
     nodes, ntri = [], 0
     for mat, idx in groups:
@@ -267,9 +284,8 @@ def sponza_scene(detail=1.0, n_lights=1):
     return nr.Scene(nodes, lights, (1, 1, 1)), cam
 
 
-def hairball_scene(strands=3000, sides=8, segments=60):
-    """~strands*sides*segments*2 triangles of thin tubes around a unit ball (hairball.scene: eye (0,.2,-5),
-    fovy 25, node pos (0,.1,0) angle (0,.1 deg,0) as an axis-angle)."""
+def hairball_geometry(strands=3000, sides=8, segments=60):
+    """~strands*sides*segments*2 triangles of thin tubes around a unit ball, in OBJ units (x4)."""
     rng = np.random.default_rng(HAIRBALL_SEED)
     # strand centre lines: start on a sphere of radius .55, wander outwards with curl
     dirs = rng.normal(size=(strands, 3))
@@ -303,6 +319,13 @@ def hairball_scene(strands=3000, sides=8, segments=60):
     dd = b + sides
     idx = np.concatenate([np.stack([a, b, dd], -1).reshape(-1, 3), np.stack([a, dd, c], -1).reshape(-1, 3)]).astype(np.uint32)
     uvs = _f32(np.stack([np.tile(np.repeat(t, sides), strands), np.tile(np.tile(np.arange(sides) / sides, segments + 1), strands)], -1))
+    return _f32(pts * 4.0), idx, uvs
+
+
+def hairball_scene(strands=3000, sides=8, segments=60):
+    """hairball.scene: eye (0,.2,-5), fovy 25, node pos (0,.1,0) angle (0,.1 deg,0) as an axis-angle."""
+    pts, idx, uvs = hairball_geometry(strands, sides, segments)
+    pts = _f32(pts * 0.25)
     mat = nr.PhongMaterial((0.1, 0.1, 0.1), (1, 1, 1), (1, 1, 1), None, None, 100.0)  # `material default`
     iso = nr.Isometry3((0.0, 0.1, 0.0), (0.0, math.radians(0.1), 0.0))
     node = nr.SceneNode(mat, 0.0, 0.0, 1.0, 1.0, iso, nr.TriMesh(pts, idx, uvs))
