@@ -40,7 +40,18 @@ enum InstanceFlags : uint32_t {
     kInstIdentityRot = 2u,   // rotation is exactly the identity: skip the ray transform
     kInstAnyHit = 4u,        // shadow TLAS only: every node behind this BLAS is opaque (alpha == 1
                              // for every hit), so the first hit within maxtoi blocks (scene.rs:328-330)
-    kInstHasUv = 8u          // the mesh(es) behind this BLAS carry uvs
+    kInstHasUv = 8u,         // the mesh(es) behind this BLAS carry uvs
+    kInstNoXform = 16u       // identity rotation AND zero translation: local space == world space
+};
+
+// Flags carried in the 3 low bits of a TLAS leaf ref (triangle leaves use them as count - 1).
+enum LeafBits : uint32_t { kLeafNoXform = 1u, kLeafAnyHit = 2u, kLeafMesh = 4u };
+
+// Compact per-instance link read when a ray enters a BLAS (8 B instead of the 136-B Instance, which is
+// only needed for rotated / translated instances and at accepted hits).
+struct InstLink {
+    int32_t blas_root;
+    uint32_t flags; // InstanceFlags
 };
 
 // TLAS leaf payload: one analytic shape, or one BLAS (a single TriMesh node, or several TriMesh
@@ -118,6 +129,8 @@ struct DScene {
     const TriUv* triuvs;      // parallel to tris (may be null if no mesh has uvs)
     const Instance* instances;        // closest-hit TLAS leaves (+ planes at the end)
     const Instance* shadow_instances; // shadow TLAS leaves (+ planes at the end)
+    const InstLink* links;            // parallel to instances
+    const InstLink* shadow_links;     // parallel to shadow_instances
     const NodeRec* node_recs;
     const double* node_aabbs;         // 6 f64 per scene node: world AABB exactly as the reference computes
                                       // geometry.bounding_volume(&transform) (scene_node.rs:41); gates accepted hits
@@ -142,6 +155,7 @@ struct DRender {
     uint32_t band_rows, band_owner, band_owners;
     uint32_t first_batch;        // 1: store into out, 0: add
     uint32_t use_rng;            // 0 when no random number can be consumed (window == 0, no area light)
+    uint32_t reverse_tiles;      // scheduling order of the wave tiles (speed only)
     double window_width;
     double eye[3];
     double m[16];                // (P V)^-1 column-major

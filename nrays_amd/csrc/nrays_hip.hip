@@ -30,6 +30,7 @@ namespace nrays {
 #define NRAYS_WAVES_PER_SIMD 2 // second __launch_bounds__ argument: caps the VGPR budget at 512 / this
 #endif
 constexpr int kTile = 16;          // a workgroup renders a 16x16 pixel tile
+constexpr int kNumCounts = kMaxGenerations + 2 + 8; // queue round counters + 8 per-XCD work counters
 constexpr int kMaxGrid = 2048;     // persistent grid: 256 CUs x 8 workgroups
 constexpr int kSpillDepth = 96;    // HBM spill entries per lane (only allocated for very deep trees)
 
@@ -87,8 +88,15 @@ constexpr int waves_per_simd(int feat) { return feat == kFeatMesh ? (NRAYS_WAVES
 
 template <bool STATS, int FEAT>
 __global__ void __launch_bounds__(kBlock, waves_per_simd(FEAT)) k_primary(DScene S, DRender R, QueueOut qo, float* __restrict__ out, DeviceCounters* ctr,
-                                                     uint32_t* spill, uint32_t tiles_x, uint32_t tiles_y, uint32_t* work_counters, uint32_t grab) {
+                                                     uint32_t* spill, uint32_t tiles_x, uint32_t tiles_y, uint32_t* work_counters, uint32_t grab,
+                                                     uint32_t* zero_counts, DeviceCounters* zero_ctr) {
     __shared__ uint32_t lds_stack[kLdsStack * kBlock];
+    // Counters are double-buffered: this launch clears the set the NEXT launch / frame will use (nothing
+    // else touches it while this kernel runs), which removes every hipMemsetAsync from the frame.
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < kNumCounts) zero_counts[threadIdx.x] = 0u;
+        if (zero_ctr && threadIdx.x < sizeof(DeviceCounters) / 4) ((uint32_t*)zero_ctr)[threadIdx.x] = 0u;
+    }
     Stack st;
     st.lds = lds_stack + threadIdx.x;
     st.spill_stride = gridDim.x * kBlock;
@@ -131,7 +139,8 @@ __global__ void __launch_bounds__(kBlock, waves_per_simd(FEAT)) k_primary(DScene
           last = first + grab < end ? first + grab : end;
           if (prefetch) pending = issue_grab(work_counters, victim, grab); // issued now, consumed after the tiles below
       }
-      for (uint32_t wt = first; wt < last; ++wt) {
+      for (uint32_t wt0 = first; wt0 < last; ++wt0) {
+        uint32_t wt = R.reverse_tiles ? nwt - 1u - wt0 : wt0;
         uint32_t tile = wt >> 2, sub = wt & 3u;
         uint32_t tx = tile % tiles_x, ty = tile / tiles_x;
         uint32_t lx = ((sub & 1u) << 3) | (lane & 7u), ly = ((sub >> 1) << 3) | (lane >> 3);
@@ -243,8 +252,11 @@ struct NraysScene {
     // per-scene transient state, grown on demand
     QueueMem queue[2];
     uint32_t queue_capacity = 0;
-    uint32_t* d_counts = nullptr;         // kMaxGenerations + 2 generation counters
-    DeviceCounters* d_counters = nullptr;
+    uint32_t* d_counts_set[2] = {nullptr, nullptr};         // double-buffered, kNumCounts each
+    DeviceCounters* d_counters_set[2] = {nullptr, nullptr}; // double-buffered per frame
+    uint32_t* d_counts = nullptr;         // set used by the last launch
+    DeviceCounters* d_counters = nullptr; // set used by the last frame
+    uint64_t launch_index = 0, frame_index = 0;
     uint32_t* d_spill = nullptr;
     bool need_spill = false;
     int features = kFeatAll;
@@ -310,9 +322,10 @@ static uint32_t tile_rows(const NraysRenderParams* p) {
 // The primary kernel is instantiated per feature set; instrumented renders and k_bounce use the
 // full-featured code (their results are identical, only slower).
 static void launch_primary(bool instrumented, int features, uint32_t grid, hipStream_t stream, const DScene& d, const DRender& R,
-                           const QueueOut& qo, float* out, DeviceCounters* ctr, uint32_t* spill, uint32_t tx, uint32_t ty, uint32_t* work, uint32_t grab) {
-#define NR_LAUNCH(F) hipLaunchKernelGGL((k_primary<false, F>), dim3(grid), dim3(kBlock), 0, stream, d, R, qo, out, ctr, spill, tx, ty, work, grab)
-    if (instrumented) { hipLaunchKernelGGL((k_primary<true, kFeatAll>), dim3(grid), dim3(kBlock), 0, stream, d, R, qo, out, ctr, spill, tx, ty, work, grab); return; }
+                           const QueueOut& qo, float* out, DeviceCounters* ctr, uint32_t* spill, uint32_t tx, uint32_t ty, uint32_t* work, uint32_t grab,
+                           uint32_t* zero_counts, DeviceCounters* zero_ctr) {
+#define NR_LAUNCH(F) hipLaunchKernelGGL((k_primary<false, F>), dim3(grid), dim3(kBlock), 0, stream, d, R, qo, out, ctr, spill, tx, ty, work, grab, zero_counts, zero_ctr)
+    if (instrumented) { hipLaunchKernelGGL((k_primary<true, kFeatAll>), dim3(grid), dim3(kBlock), 0, stream, d, R, qo, out, ctr, spill, tx, ty, work, grab, zero_counts, zero_ctr); return; }
     switch (features) {
     case 1: NR_LAUNCH(1); break;
     case 2: NR_LAUNCH(2); break;
@@ -368,18 +381,23 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
 
     const int slot = (int)(sc->frames_recorded % NraysScene::kRing);
     HIP_TRY(hipEventRecord(sc->ev_begin[slot], stream));
-    HIP_TRY(hipMemsetAsync(sc->d_counters, 0, sizeof(DeviceCounters), stream));
+    sc->d_counters = sc->d_counters_set[sc->frame_index & 1];
+    DeviceCounters* next_ctr = sc->d_counters_set[(sc->frame_index + 1) & 1];
+    sc->frame_index++;
     R.use_rng = (p->window_width != 0.0 || sc->host.any_area_light) ? 1u : 0u;
+    R.reverse_tiles = 0;
+    if (const char* e = getenv("NRAYS_REVERSE")) R.reverse_tiles = (uint32_t)atoi(e);
     bool first_primary = true;
     for (uint32_t s0 = 0; s0 < p->ray_per_pixel; s0 += batch) {
         R.sample_begin = s0; R.sample_end = std::min<uint32_t>(p->ray_per_pixel, s0 + batch);
         R.first_batch = s0 == 0 ? 1u : 0u;
-        // zeroes the queue counters and the 8 per-XCD work counters that follow them
-        HIP_TRY(hipMemsetAsync(sc->d_counts, 0, (kMaxGenerations + 2 + 8) * sizeof(uint32_t), stream));
+        sc->d_counts = sc->d_counts_set[sc->launch_index & 1];
+        uint32_t* next_counts = sc->d_counts_set[(sc->launch_index + 1) & 1];
+        sc->launch_index++;
         QueueOut qo; qo.q = sc->queue[1].q; qo.capacity = queued ? sc->queue_capacity : 0; qo.count = sc->d_counts + 1;
         qo.overflow = &sc->d_counters->overflow;
         if (first_primary) HIP_TRY(hipEventRecord(sc->ev_pbegin[slot], stream));
-        launch_primary(instrumented, sc->features, grid_primary, stream, sc->d, R, qo, d_out, sc->d_counters, sc->d_spill, tiles_x, tiles_y, sc->d_counts + kMaxGenerations + 2, grab);
+        launch_primary(instrumented, sc->features, grid_primary, stream, sc->d, R, qo, d_out, sc->d_counters, sc->d_spill, tiles_x, tiles_y, sc->d_counts + kMaxGenerations + 2, grab, next_counts, R.first_batch ? next_ctr : nullptr);
         HIP_TRY(hipGetLastError());
         if (first_primary) {
             HIP_TRY(hipEventRecord(sc->ev_pend[slot], stream));
@@ -446,6 +464,8 @@ int nrays_scene_create(const NraysSceneDesc* desc, NraysScene** out_scene) {
     if ((rc = upload(sc, h.triuvs, &sc->d.triuvs)) != NRAYS_OK) return bail(rc);
     if ((rc = upload(sc, h.instances, &sc->d.instances)) != NRAYS_OK) return bail(rc);
     if ((rc = upload(sc, h.shadow_instances, &sc->d.shadow_instances)) != NRAYS_OK) return bail(rc);
+    if ((rc = upload(sc, h.links, &sc->d.links)) != NRAYS_OK) return bail(rc);
+    if ((rc = upload(sc, h.shadow_links, &sc->d.shadow_links)) != NRAYS_OK) return bail(rc);
     if ((rc = upload(sc, h.node_recs, &sc->d.node_recs)) != NRAYS_OK) return bail(rc);
     if ((rc = upload(sc, h.node_aabbs, &sc->d.node_aabbs)) != NRAYS_OK) return bail(rc);
     if ((rc = upload(sc, h.materials, &sc->d.materials)) != NRAYS_OK) return bail(rc);
@@ -471,13 +491,17 @@ int nrays_scene_create(const NraysSceneDesc* desc, NraysScene** out_scene) {
     // release bulk host copies
     std::vector<BvhNode>().swap(h.nodes); std::vector<TriRec>().swap(h.tris); std::vector<TriUv>().swap(h.triuvs);
 
-    if (hipMalloc((void**)&sc->d_counts, (kMaxGenerations + 2 + 8) * sizeof(uint32_t)) != hipSuccess ||
-        hipMalloc((void**)&sc->d_counters, sizeof(DeviceCounters)) != hipSuccess ||
-        hipMalloc((void**)&sc->d_counters_primary, sizeof(DeviceCounters)) != hipSuccess)
+    for (int k = 0; k < 2; ++k) {
+        if (hipMalloc((void**)&sc->d_counts_set[k], kNumCounts * sizeof(uint32_t)) != hipSuccess ||
+            hipMalloc((void**)&sc->d_counters_set[k], sizeof(DeviceCounters)) != hipSuccess)
+            return bail(fail(NRAYS_ERR_OOM, "counter allocation failed"));
+        if (hipMemset(sc->d_counts_set[k], 0, kNumCounts * sizeof(uint32_t)) != hipSuccess ||
+            hipMemset(sc->d_counters_set[k], 0, sizeof(DeviceCounters)) != hipSuccess)
+            return bail(fail(NRAYS_ERR_HIP, "counter memset failed"));
+    }
+    sc->d_counts = sc->d_counts_set[0]; sc->d_counters = sc->d_counters_set[0];
+    if (hipMalloc((void**)&sc->d_counters_primary, sizeof(DeviceCounters)) != hipSuccess)
         return bail(fail(NRAYS_ERR_OOM, "counter allocation failed"));
-    if (hipMemset(sc->d_counts, 0, (kMaxGenerations + 2 + 8) * sizeof(uint32_t)) != hipSuccess ||
-        hipMemset(sc->d_counters, 0, sizeof(DeviceCounters)) != hipSuccess)
-        return bail(fail(NRAYS_ERR_HIP, "counter memset failed"));
     if (hipStreamCreate(&sc->own_stream) != hipSuccess) return bail(fail(NRAYS_ERR_HIP, "stream creation failed"));
     for (int k = 0; k < NraysScene::kRing; ++k)
         if (hipEventCreate(&sc->ev_begin[k]) != hipSuccess || hipEventCreate(&sc->ev_pbegin[k]) != hipSuccess ||
@@ -493,8 +517,10 @@ void nrays_scene_destroy(NraysScene* sc) {
     if (sc->have_last) (void)hipStreamSynchronize(sc->last_stream);
     for (void* p : sc->allocs) (void)hipFree(p);
     for (int k = 0; k < 2; ++k) if (sc->queue[k].block) (void)hipFree(sc->queue[k].block);
-    if (sc->d_counts) (void)hipFree(sc->d_counts);
-    if (sc->d_counters) (void)hipFree(sc->d_counters);
+    for (int k = 0; k < 2; ++k) {
+        if (sc->d_counts_set[k]) (void)hipFree(sc->d_counts_set[k]);
+        if (sc->d_counters_set[k]) (void)hipFree(sc->d_counters_set[k]);
+    }
     if (sc->d_spill) (void)hipFree(sc->d_spill);
     if (sc->d_frame) (void)hipFree(sc->d_frame);
     if (sc->d_counters_primary) (void)hipFree(sc->d_counters_primary);

@@ -181,6 +181,17 @@ int32_t append_tlas(std::vector<Instance>& insts, const std::vector<PrimBounds>&
     for (size_t k = 0; k < bvh.order.size(); ++k) re[k] = insts[bvh.order[k]];
     insts.swap(re);
     rebase_bvh(bvh, (int32_t)out.nodes.size(), 0);
+    // the 3 low bits of a TLAS leaf ref carry the instance's LeafBits
+    auto tag = [&](int32_t ref) -> int32_t {
+        if (ref >= 0 || ref == kEmptyChild) return ref;
+        uint32_t first = ((uint32_t)~ref) >> 3;
+        const Instance& in = insts[first];
+        uint32_t bits = (in.kind == NRAYS_SHAPE_TRIMESH ? kLeafMesh : 0u) | ((in.flags & kInstAnyHit) ? kLeafAnyHit : 0u) |
+                        ((in.kind == NRAYS_SHAPE_TRIMESH && (in.flags & kInstNoXform)) ? kLeafNoXform : 0u);
+        return ~(int32_t)((first << 3) | bits);
+    };
+    for (BvhNode& n : bvh.nodes) { n.left = tag(n.left); n.right = tag(n.right); }
+    bvh.root = tag(bvh.root);
     out.max_bvh_depth = std::max(out.max_bvh_depth, bvh.max_depth);
     out.nodes.insert(out.nodes.end(), bvh.nodes.begin(), bvh.nodes.end());
     return bvh.root;
@@ -283,6 +294,7 @@ int build_host_scene(const NraysSceneDesc* d, HostScene& out, std::string& err) 
         for (int k = 0; k < 3; ++k) { in.trans[k] = n.translation[k]; in.params[k] = n.params[k]; }
         in.kind = n.shape_kind;
         in.flags = (n.solid ? kInstSolid : 0u) | (info[ni].identity ? kInstIdentityRot : 0u) | (info[ni].has_uv ? kInstHasUv : 0u);
+        if (info[ni].identity && n.translation[0] == 0.0 && n.translation[1] == 0.0 && n.translation[2] == 0.0) in.flags |= kInstNoXform;
         in.node_id = (int32_t)ni; in.blas_root = kEmptyChild;
         return in;
     };
@@ -369,6 +381,8 @@ int build_host_scene(const NraysSceneDesc* d, HostScene& out, std::string& err) 
     }
     out.instances.swap(cinst);
     out.shadow_instances.swap(sinst);
+    for (const Instance& in : out.instances) out.links.push_back(InstLink{in.blas_root, in.flags});
+    for (const Instance& in : out.shadow_instances) out.shadow_links.push_back(InstLink{in.blas_root, in.flags});
     return NRAYS_OK;
 }
 

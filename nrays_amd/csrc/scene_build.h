@@ -20,6 +20,7 @@ struct HostScene {
     std::vector<TriUv> triuvs;
     std::vector<Instance> instances;         // closest TLAS order, planes appended at the end
     std::vector<Instance> shadow_instances;  // shadow TLAS order, planes appended at the end
+    std::vector<InstLink> links, shadow_links; // parallel to instances / shadow_instances
     std::vector<int32_t> planes, shadow_planes;
     std::vector<NodeRec> node_recs;
     std::vector<double> node_aabbs;          // 6 per node (mins, maxs), reference arithmetic

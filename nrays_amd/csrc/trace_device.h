@@ -488,15 +488,16 @@ struct Hit {
 // slab test runs in f32 with explicit error margins so that it is a SUPERSET of the f64 slab test
 // (ncollide ray_aabb, called at src/scene.rs:276) and can therefore never change a result:
 //   o32 = fl(o)            |o - o32| <= |o| 2^-24          -> absolute margin e = |o32 * inv32| 2^-22 per axis
-//   inv32 = fl(1/d)        relative error <= 2^-24 (+2^-53)
-//   t = fl(fl(b - o32) * inv32)  relative error <= 3 * 2^-24 -> relative slack 2^-21 on the final compare
+//   inv32 = rcp(fl(d))     relative error <= 2^-24 (rounding of d) + 2^-23 (v_rcp_f32, 1 ulp)
+//   t = fl(fl(b - o32) * inv32)  relative error <= 5 * 2^-24 = 3.0e-7 -> relative slack 2^-21 = 4.8e-7 on the final compare
 // A zero direction component uses the finite inverse 1e30 (no NaN from 0 * inf; the margin then
 // decides inside/outside of the slab conservatively).
 struct RayF {
     float ox, oy, oz, ix, iy, iz, ex, ey, ez;
 };
 NR_DEV float inv_f32(double d) {
-    float r = d == 0.0 ? 1e30f : (float)(1.0 / d);
+    float x = (float)d;
+    float r = x == 0.0f ? 1e30f : __builtin_amdgcn_rcpf(x);
     if (!(fabsf(r) < 1e30f)) r = copysignf(1e30f, r);
     return r;
 }
@@ -614,6 +615,7 @@ NR_DEV bool traverse(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, Hit&
     constexpr bool kAnalytic = (FEAT & kFeatAnalytic) != 0, kMesh = (FEAT & kFeatMesh) != 0;
     constexpr bool kAlpha = (FEAT & kFeatAlphaShadow) != 0; // shadow mode: otherwise every hit within tlimit blocks
     const Instance* insts = SHADOW ? S.shadow_instances : S.instances;
+    const InstLink* links = SHADOW ? S.shadow_links : S.links;
     double bt = SHADOW ? tlimit : kDblMax;
     unsigned long long bkey = ~0ULL;
     bool bhit = false;
@@ -632,28 +634,13 @@ NR_DEV bool traverse(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, Hit&
         for (uint32_t p = 0; p < S.num_planes; ++p) st.push(~(int32_t)(((uint32_t)planes[p]) << 3));
     }
     int32_t cur = SHADOW ? S.shadow_root : S.closest_root;
+    if (cur == kEmptyChild && st.sp) cur = st.pop();
 
+    // "while-while" traversal: the wave first runs internal-node steps only (one 64-byte fetch and two
+    // f32 box tests per step) until every lane holds a leaf or is done, then runs the leaf code, instead
+    // of serialising node / instance / triangle / sentinel code paths in every iteration.
     for (;;) {
-        if (cur == kEmptyChild) {
-            if (st.sp == 0) break;
-            cur = st.pop();
-            if (kMesh && cur == kSentinel) { // the BLAS of `cur_inst` is exhausted: back to world space
-                in_blas = false;
-                co = o; cd = d; rf = make_rayf(o, d);
-                if (SHADOW && kAlpha && !(cur_flags & kInstAnyHit)) {
-                    if (bhit) {
-                        Hit h; h.t = bt; h.inst = cur_inst; h.prim = bprim;
-                        Isect is; uint32_t node_id;
-                        resolve_hit<true, FEAT>(S, o, d, h, is, node_id);
-                        if (shadow_node_hit<STATS>(S, node_id, is, filter, cnt)) return true;
-                    }
-                    bt = tlimit; bkey = ~0ULL; bhit = false; btf = best_f32(bt);
-                }
-                cur = kEmptyChild;
-            }
-            continue;
-        }
-        if (cur >= 0) { // internal node: one 64-byte fetch, two box tests
+        while (cur >= 0) {
             const float4* q = (const float4*)(S.nodes + cur);
             float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
             int32_t left = __float_as_int(q3.x), right = __float_as_int(q3.y);
@@ -664,26 +651,68 @@ NR_DEV bool traverse(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, Hit&
             if (hl && hr) {
                 if (tr < tl) { st.push(left); cur = right; }
                 else { st.push(right); cur = left; }
-            } else cur = hl ? left : (hr ? right : kEmptyChild);
+            } else if (hl || hr) cur = hl ? left : right;
+            else cur = st.sp ? st.pop() : kEmptyChild;
+        }
+        if (cur == kEmptyChild) break;
+        if (kMesh && cur == kSentinel) { // the BLAS of `cur_inst` is exhausted: back to world space
+            in_blas = false;
+            if (!(cur_flags & kInstNoXform)) { co = o; cd = d; rf = make_rayf(o, d); }
+            if (SHADOW && kAlpha && !(cur_flags & kInstAnyHit)) {
+                if (bhit) {
+                    Hit h; h.t = bt; h.inst = cur_inst; h.prim = bprim;
+                    Isect is; uint32_t node_id;
+                    resolve_hit<true, FEAT>(S, o, d, h, is, node_id);
+                    if (shadow_node_hit<STATS>(S, node_id, is, filter, cnt)) return true;
+                }
+                bt = tlimit; bkey = ~0ULL; bhit = false; btf = best_f32(bt);
+            }
+            cur = st.sp ? st.pop() : kEmptyChild;
             continue;
         }
-        // leaf
+        // leaf: ~cur = (first << 3) | bits.  Triangle leaves: bits = count - 1.  TLAS leaves: bits = kLeaf* flags.
         uint32_t lv = (uint32_t)~cur;
-        uint32_t first = lv >> 3, count = (lv & 7u) + 1u;
-        if (!kMesh || !in_blas) { // TLAS leaf = one instance
-            const Instance& in = insts[first];
-            if (kMesh && (!kAnalytic || in.kind == NRAYS_SHAPE_TRIMESH)) {
-                cur_inst = first; cur_flags = in.flags;
+        uint32_t first = lv >> 3, bits = lv & 7u;
+        if (kMesh && in_blas) { // triangle leaf
+#pragma nounroll
+            for (uint32_t k = 0; k <= bits; ++k) {
+                const float4* tq = (const float4*)(S.tris + first + k);
+                float4 t0 = tq[0], t1 = tq[1], t2 = tq[2];
+                if (STATS) cnt.tri++;
+                double toi;
+                d3 va = D3(t0.x, t0.y, t0.z), vb = D3(t1.x, t1.y, t1.z), vc = D3(t2.x, t2.y, t2.z);
+                if (cast_triangle(va, vb, vc, co, cd, toi, nullptr, nullptr) && tri_aabb_pass(va, vb, vc, co, cd) &&
+                    node_aabb_pass(S, __float_as_uint(t0.w), o, d)) {
+                    if (SHADOW && (!kAlpha || (cur_flags & kInstAnyHit))) { if (toi <= tlimit) return true; }
+                    else {
+                        unsigned long long key = SHADOW ? (unsigned long long)__float_as_uint(t1.w)
+                                                        : (((unsigned long long)__float_as_uint(t0.w) << 32) | __float_as_uint(t1.w));
+                        if (toi < bt || (toi == bt && key < bkey)) { bt = toi; bkey = key; bhit = true; binst = cur_inst; bprim = first + k; btf = best_f32(bt); }
+                    }
+                }
+            }
+            cur = st.sp ? st.pop() : kEmptyChild;
+            continue;
+        }
+        if (kMesh && (!kAnalytic || (bits & kLeafMesh))) { // TLAS leaf: a BLAS
+            cur_inst = first;
+            InstLink link = links[first];
+            cur_flags = link.flags;
+            if (!(bits & kLeafNoXform)) { // rotated / translated instance: move the ray into its local frame
+                const Instance& in = insts[first];
                 Xform m; load_xform(in, m);
                 if (in.flags & kInstIdentityRot) { co = o - m.t; cd = d; }
                 else { co = inv_rot(m, o - m.t); cd = inv_rot(m, d); }
                 rf = make_rayf(co, cd);
-                in_blas = true;
-                st.push(kSentinel);
-                cur = in.blas_root;
-                continue;
             }
-            if (!kAnalytic) { cur = kEmptyChild; continue; }
+            in_blas = true;
+            st.push(kSentinel);
+            cur = link.blas_root;
+            if (cur == kEmptyChild) cur = st.pop();
+            continue;
+        }
+        if (kAnalytic) { // TLAS leaf: an analytic shape (or a plane pseudo-leaf)
+            const Instance& in = insts[first];
             if (STATS) cnt.prim++;
             Isect is;
             if (cast_analytic(in, o, d, is) && (in.kind == NRAYS_SHAPE_PLANE || node_aabb_pass(S, (uint32_t)in.node_id, o, d))) {
@@ -697,29 +726,8 @@ NR_DEV bool traverse(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, Hit&
                     if (is.toi < bt || (is.toi == bt && key < bkey)) { bt = is.toi; bkey = key; bhit = true; binst = first; bprim = 0; btf = best_f32(bt); }
                 }
             }
-            cur = kEmptyChild;
-            continue;
         }
-        // triangle leaf
-        if (!kMesh) { cur = kEmptyChild; continue; }
-#pragma nounroll
-        for (uint32_t k = 0; k < count; ++k) {
-            const float4* tq = (const float4*)(S.tris + first + k);
-            float4 t0 = tq[0], t1 = tq[1], t2 = tq[2];
-            if (STATS) cnt.tri++;
-            double toi;
-            d3 va = D3(t0.x, t0.y, t0.z), vb = D3(t1.x, t1.y, t1.z), vc = D3(t2.x, t2.y, t2.z);
-            if (cast_triangle(va, vb, vc, co, cd, toi, nullptr, nullptr) && tri_aabb_pass(va, vb, vc, co, cd) &&
-                node_aabb_pass(S, __float_as_uint(t0.w), o, d)) {
-                if (SHADOW && (!kAlpha || (cur_flags & kInstAnyHit))) { if (toi <= tlimit) return true; }
-                else {
-                    unsigned long long key = SHADOW ? (unsigned long long)__float_as_uint(t1.w)
-                                                    : (((unsigned long long)__float_as_uint(t0.w) << 32) | __float_as_uint(t1.w));
-                    if (toi < bt || (toi == bt && key < bkey)) { bt = toi; bkey = key; bhit = true; binst = cur_inst; bprim = first + k; btf = best_f32(bt); }
-                }
-            }
-        }
-        cur = kEmptyChild;
+        cur = st.sp ? st.pop() : kEmptyChild;
     }
 
     if (SHADOW) return false;
