@@ -43,15 +43,20 @@ constexpr int kBins = 16;
 #endif
 constexpr float kPrimCost = NR_PRIM_COST;
 
+struct Node2 { // binary node produced by the SAH build, collapsed into 4-wide BvhNodes afterwards
+    float lmin[3], lmax[3], rmin[3], rmax[3];
+    int32_t left, right;
+};
+
 struct Builder {
     const std::vector<PrimBounds>& prims;
     std::vector<uint32_t>& order;
-    std::vector<BvhNode>& nodes;
+    std::vector<Node2>& nodes;
     std::vector<float> cent; // 3 per prim
     int max_leaf;
     int max_depth = 0;
 
-    Builder(const std::vector<PrimBounds>& p, std::vector<uint32_t>& o, std::vector<BvhNode>& n, int ml)
+    Builder(const std::vector<PrimBounds>& p, std::vector<uint32_t>& o, std::vector<Node2>& n, int ml)
         : prims(p), order(o), nodes(n), max_leaf(ml) {
         cent.resize(p.size() * 3);
         for (size_t i = 0; i < p.size(); ++i)
@@ -122,9 +127,57 @@ struct Builder {
         Box lb, rb;
         int32_t l = build(first, mid - first, lb, depth + 1);
         int32_t r = build(mid, first + count - mid, rb, depth + 1);
-        BvhNode& n = nodes[me];
+        Node2& n = nodes[me];
         for (int a = 0; a < 3; ++a) { n.lmin[a] = lb.mn[a]; n.lmax[a] = lb.mx[a]; n.rmin[a] = rb.mn[a]; n.rmax[a] = rb.mx[a]; }
-        n.left = l; n.right = r; n.pad[0] = n.pad[1] = 0;
+        n.left = l; n.right = r;
+        return me;
+    }
+};
+
+// Collapses the binary tree rooted at binary node `n2` into 4-wide nodes; returns the new node index.
+struct Collapser {
+    const std::vector<Node2>& n2;
+    std::vector<BvhNode>& out;
+    int max_depth = 0;
+    struct Slot { float mn[3], mx[3]; int32_t ref; };
+    static float area(const Slot& s) {
+        float dx = s.mx[0] - s.mn[0], dy = s.mx[1] - s.mn[1], dz = s.mx[2] - s.mn[2];
+        return dx * dy + dy * dz + dz * dx;
+    }
+    int32_t collapse(int32_t root, int depth) {
+        max_depth = std::max(max_depth, depth);
+        std::vector<Slot> slots;
+        auto push_children = [&](int32_t node) {
+            const Node2& b = n2[node];
+            Slot l, r;
+            for (int a = 0; a < 3; ++a) { l.mn[a] = b.lmin[a]; l.mx[a] = b.lmax[a]; r.mn[a] = b.rmin[a]; r.mx[a] = b.rmax[a]; }
+            l.ref = b.left; r.ref = b.right;
+            slots.push_back(l); slots.push_back(r);
+        };
+        push_children(root);
+        while (slots.size() < 4) { // open the internal child with the largest box
+            int best = -1; float ba = -1.f;
+            for (size_t k = 0; k < slots.size(); ++k) if (slots[k].ref >= 0 && area(slots[k]) > ba) { ba = area(slots[k]); best = (int)k; }
+            if (best < 0) break;
+            int32_t node = slots[best].ref;
+            slots.erase(slots.begin() + best);
+            push_children(node);
+        }
+        int32_t me = (int32_t)out.size();
+        out.emplace_back();
+        std::vector<int32_t> refs(slots.size());
+        for (size_t k = 0; k < slots.size(); ++k) refs[k] = slots[k].ref >= 0 ? collapse(slots[k].ref, depth + 1) : slots[k].ref;
+        BvhNode& n = out[me];
+        for (int k = 0; k < 4; ++k) {
+            if (k < (int)slots.size()) {
+                for (int a = 0; a < 3; ++a) { n.box[k][a] = slots[k].mn[a]; n.box[k][3 + a] = slots[k].mx[a]; }
+                n.child[k] = refs[k];
+            } else {
+                for (int a = 0; a < 3; ++a) { n.box[k][a] = std::numeric_limits<float>::infinity(); n.box[k][3 + a] = -std::numeric_limits<float>::infinity(); }
+                n.child[k] = kEmptyChild;
+            }
+            n.pad[k] = 0;
+        }
         return me;
     }
 };
@@ -138,19 +191,21 @@ BuiltBvh build_bvh(const std::vector<PrimBounds>& prims, int max_leaf) {
     for (size_t i = 0; i < prims.size(); ++i) out.order[i] = (uint32_t)i;
     if (prims.empty()) { out.root = kEmptyChild; return out; }
     max_leaf = std::min(std::max(max_leaf, 1), 8);
-    out.nodes.reserve(prims.size());
-    Builder b(prims, out.order, out.nodes, max_leaf);
+    std::vector<Node2> binary;
+    binary.reserve(prims.size());
+    Builder b(prims, out.order, binary, max_leaf);
     Box bounds;
-    out.root = b.build(0, (uint32_t)prims.size(), bounds, 0);
-    out.max_depth = b.max_depth;
+    int32_t root2 = b.build(0, (uint32_t)prims.size(), bounds, 0);
+    if (root2 < 0) { out.root = root2; return out; } // a single leaf
+    Collapser c{binary, out.nodes};
+    out.root = c.collapse(root2, 0);
+    out.max_depth = c.max_depth;
     return out;
 }
 
 void rebase_bvh(BuiltBvh& bvh, int32_t node_base, uint32_t prim_base) {
-    for (BvhNode& n : bvh.nodes) {
-        n.left = rebase_ref(n.left, node_base, prim_base);
-        n.right = rebase_ref(n.right, node_base, prim_base);
-    }
+    for (BvhNode& n : bvh.nodes)
+        for (int k = 0; k < 4; ++k) n.child[k] = rebase_ref(n.child[k], node_base, prim_base);
     bvh.root = rebase_ref(bvh.root, node_base, prim_base);
 }
 

@@ -1,5 +1,5 @@
-// bvh_build.h — host-side binned-SAH BVH2 builder producing the 64-byte two-child-box node layout
-// of device_types.h.  Replaces ncollide's BVT::new_balanced (called at src/scene.rs:126 and inside
+// bvh_build.h — host-side binned-SAH builder (binary build, then collapse) producing the 128-byte
+// 4-wide node layout of device_types.h.  Replaces ncollide's BVT::new_balanced (called at src/scene.rs:126 and inside
 // TriMesh::new, examples/loader3d.rs:695).  The tree shape differs from the reference's median
 // split on purpose: closest-hit / shadow results do not depend on the tree, only node-visit
 // counts do (DESIGN.md reports both trees' counts).

@@ -5,19 +5,22 @@
 
 namespace nrays {
 
-// One BVH2 node holding BOTH child boxes (64 B = 4 x dwordx4).  A fetch of one node pays for two
-// AABB tests; bounds are f32 rounded OUTWARD from the f64 geometry, so an f64 slab test against
-// them is a superset of the reference's f64 test (ncollide AABB::toi_with_ray, src/scene.rs:276).
-// child >= 0: index of an internal node; child < 0: leaf, ~child = (first << 3) | (count - 1) for
-// triangle leaves (BLAS) and ~child = instance index for TLAS leaves.  An absent child has an
-// inverted box (min = +inf, max = -inf) and child = kEmptyChild.
+// One 4-wide BVH node (128 B = 8 x dwordx4): the boxes of up to four children followed by their refs.
+// The tree is built as a binned-SAH binary tree and collapsed (the child with the largest box is
+// replaced by its own two children until four slots are used): the traversal is bound by the chain of
+// dependent node fetches, and a 4-wide node halves that chain.  One fetch pays for four AABB tests
+// (32 B each, the SURVEY 8d unit).  Bounds are f32 rounded OUTWARD from the f64 geometry, so the
+// conservative f32 slab test against them is a superset of the reference's f64 test (ncollide
+// AABB::toi_with_ray, src/scene.rs:276).
+// child >= 0: index of an internal node; child < 0: leaf, ~child = (first << 3) | bits, where bits =
+// count - 1 for triangle leaves (BLAS) and LeafBits for TLAS leaves (first = instance index).  An
+// absent child has an inverted box (min = +inf, max = -inf) and child = kEmptyChild.
 struct BvhNode {
-    float lmin[3], lmax[3];
-    float rmin[3], rmax[3];
-    int32_t left, right;
-    uint32_t pad[2];
+    float box[4][6]; // child k: min.xyz, max.xyz
+    int32_t child[4];
+    uint32_t pad[4];
 };
-static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
+static_assert(sizeof(BvhNode) == 128, "BvhNode must be 128 bytes");
 constexpr int32_t kEmptyChild = (int32_t)0x80000000;
 
 // Triangle record, 48 B = 3 x dwordx4 (36 B of vertex data + ids riding in the .w lanes):
@@ -104,6 +107,8 @@ struct DeviceCounters {
     unsigned long long node_tests, tri_tests, prim_tests, hit_records, tex_samples;
     unsigned int overflow;  // set when a continuation queue ran out of capacity
     unsigned int max_depth; // deepest trace depth reached (= number of continuation generations)
+    unsigned int max_chain_nodes; // instrumented: most AABB tests spent on one pixel's chain
+    unsigned int pad;
 };
 
 constexpr int kMaxGenerations = 64; // hard cap on trace depth (reference recursion is unbounded, scene.rs:246)

@@ -61,12 +61,13 @@ __device__ __forceinline__ uint32_t issue_grab(uint32_t* work_counters, uint32_t
 
 __device__ __forceinline__ void flush_counters(DeviceCounters* ctr, const Cnt& c, bool stats) {
     // wave-level reduction, then one atomic per wave and class
-    unsigned sh = c.shadow, rl = c.refl, rf = c.refr, md = c.max_depth;
+    unsigned sh = c.shadow, rl = c.refl, rf = c.refr, md = c.max_depth, mc = c.max_chain_nodes;
     unsigned nd = c.node, tr = c.tri, pr = c.prim, ht = c.hit, tx = c.tex;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         sh += __shfl_down(sh, off); rl += __shfl_down(rl, off); rf += __shfl_down(rf, off);
         unsigned om = __shfl_down(md, off); md = om > md ? om : md;
+        if (stats) { unsigned oc = __shfl_down(mc, off); mc = oc > mc ? oc : mc; }
         if (stats) { nd += __shfl_down(nd, off); tr += __shfl_down(tr, off); pr += __shfl_down(pr, off); ht += __shfl_down(ht, off); tx += __shfl_down(tx, off); }
     }
     if (__lane_id() == 0) {
@@ -74,6 +75,7 @@ __device__ __forceinline__ void flush_counters(DeviceCounters* ctr, const Cnt& c
         if (rl) atomicAdd(&ctr->rays_reflection, (unsigned long long)rl);
         if (rf) atomicAdd(&ctr->rays_refraction, (unsigned long long)rf);
         if (md) atomicMax(&ctr->max_depth, md);
+        if (stats && mc) atomicMax(&ctr->max_chain_nodes, mc);
         if (stats) {
             atomicAdd(&ctr->node_tests, (unsigned long long)nd); atomicAdd(&ctr->tri_tests, (unsigned long long)tr);
             atomicAdd(&ctr->prim_tests, (unsigned long long)pr); atomicAdd(&ctr->hit_records, (unsigned long long)ht);
@@ -102,7 +104,7 @@ __global__ void __launch_bounds__(kBlock, waves_per_simd(FEAT)) k_primary(DScene
     st.spill_stride = gridDim.x * kBlock;
     st.spill = spill ? spill + (size_t)blockIdx.x * kBlock + threadIdx.x : nullptr;
     st.sp = 0;
-    Cnt cnt; cnt.node = cnt.tri = cnt.prim = cnt.hit = cnt.tex = cnt.shadow = cnt.refl = cnt.refr = cnt.max_depth = 0;
+    Cnt cnt; cnt.node = cnt.tri = cnt.prim = cnt.hit = cnt.tex = cnt.shadow = cnt.refl = cnt.refr = cnt.max_depth = cnt.max_chain_nodes = 0;
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t nwt = tiles_x * tiles_y * 4u; // wave tiles: 4 per 16x16 block
@@ -157,7 +159,9 @@ __global__ void __launch_bounds__(kBlock, waves_per_simd(FEAT)) k_primary(DScene
         for (uint32_t s = R.sample_begin; s < R.sample_end; ++s) {
             RayState ray;
             generate_primary(R, i, j, s, pix, ray);
+            unsigned node_before = cnt.node;
             f3 c = trace_chain<STATS, FEAT>(S, st, active, ray, 0u, R.max_depth, qo, cnt);
+            if (STATS) { unsigned dn = cnt.node - node_before; if (dn > cnt.max_chain_nodes) cnt.max_chain_nodes = dn; }
             tot.x = tot.x + c.x; tot.y = tot.y + c.y; tot.z = tot.z + c.z;
         }
         if (active) {
@@ -184,7 +188,7 @@ __global__ void __launch_bounds__(kBlock, NRAYS_WAVES_PER_SIMD) k_bounce(DScene 
     st.spill_stride = gridDim.x * kBlock;
     st.spill = spill ? spill + (size_t)blockIdx.x * kBlock + threadIdx.x : nullptr;
     st.sp = 0;
-    Cnt cnt; cnt.node = cnt.tri = cnt.prim = cnt.hit = cnt.tex = cnt.shadow = cnt.refl = cnt.refr = cnt.max_depth = 0;
+    Cnt cnt; cnt.node = cnt.tri = cnt.prim = cnt.hit = cnt.tex = cnt.shadow = cnt.refl = cnt.refr = cnt.max_depth = cnt.max_chain_nodes = 0;
     uint32_t n = *count_in;
     if (n > capacity) n = capacity;
     for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) { // block-uniform trip count
@@ -326,13 +330,14 @@ static void launch_primary(bool instrumented, int features, uint32_t grid, hipSt
                            uint32_t* zero_counts, DeviceCounters* zero_ctr) {
 #define NR_LAUNCH(F) hipLaunchKernelGGL((k_primary<false, F>), dim3(grid), dim3(kBlock), 0, stream, d, R, qo, out, ctr, spill, tx, ty, work, grab, zero_counts, zero_ctr)
     if (instrumented) { hipLaunchKernelGGL((k_primary<true, kFeatAll>), dim3(grid), dim3(kBlock), 0, stream, d, R, qo, out, ctr, spill, tx, ty, work, grab, zero_counts, zero_ctr); return; }
-    switch (features) {
+    switch (features) { // bit 8 (double branching) only with its prerequisite bit 4 (non-opaque nodes)
     case 1: NR_LAUNCH(1); break;
     case 2: NR_LAUNCH(2); break;
     case 3: NR_LAUNCH(3); break;
     case 5: NR_LAUNCH(5); break;
     case 6: NR_LAUNCH(6); break;
-    default: NR_LAUNCH(7); break;
+    case 7: NR_LAUNCH(7); break;
+    default: NR_LAUNCH(15); break;
     }
 #undef NR_LAUNCH
 }
@@ -486,7 +491,7 @@ int nrays_scene_create(const NraysSceneDesc* desc, NraysScene** out_scene) {
     sc->d.num_planes = (uint32_t)h.planes.size(); sc->d.num_lights = (uint32_t)h.lights.size();
     for (int a = 0; a < 3; ++a) sc->d.background[a] = h.background[a];
     // stack bound: one deferred sibling per level of TLAS and BLAS, plus the sentinel
-    sc->need_spill = (2 * h.max_bvh_depth + 4) > kLdsStack;
+    sc->need_spill = (6 * h.max_bvh_depth + 4) > kLdsStack; // up to 3 deferred siblings per level, TLAS + BLAS
     sc->features = h.features ? h.features : kFeatAll;
     // release bulk host copies
     std::vector<BvhNode>().swap(h.nodes); std::vector<TriRec>().swap(h.tris); std::vector<TriUv>().swap(h.triuvs);
@@ -559,6 +564,7 @@ int nrays_get_stats(NraysScene* sc, NraysStats* out) {
     out->rays_primary = sc->last_primary;
     fill_counters(out, c);
     out->generations = c.max_depth; out->instrumented = sc->last_instrumented ? 1u : 0u;
+    out->reserved = c.max_chain_nodes; // instrumented renders: most AABB tests spent on one pixel's whole chain
     // average the event timings of the frames recorded since the previous call (at most kRing)
     uint64_t first = sc->frames_reported;
     if (sc->frames_recorded - first > (uint64_t)NraysScene::kRing) first = sc->frames_recorded - NraysScene::kRing;

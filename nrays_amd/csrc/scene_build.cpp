@@ -190,7 +190,7 @@ int32_t append_tlas(std::vector<Instance>& insts, const std::vector<PrimBounds>&
                         ((in.kind == NRAYS_SHAPE_TRIMESH && (in.flags & kInstNoXform)) ? kLeafNoXform : 0u);
         return ~(int32_t)((first << 3) | bits);
     };
-    for (BvhNode& n : bvh.nodes) { n.left = tag(n.left); n.right = tag(n.right); }
+    for (BvhNode& n : bvh.nodes) for (int k = 0; k < 4; ++k) n.child[k] = tag(n.child[k]);
     bvh.root = tag(bvh.root);
     out.max_bvh_depth = std::max(out.max_bvh_depth, bvh.max_depth);
     out.nodes.insert(out.nodes.end(), bvh.nodes.begin(), bvh.nodes.end());
@@ -371,6 +371,7 @@ int build_host_scene(const NraysSceneDesc* d, HostScene& out, std::string& err) 
             if (!info[i].opaque) f |= 4;
         }
         if (f == 4 || f == 0) f |= 1; // empty scenes take the lightest kernel
+        if (out.any_double_branch) f = 15; // reflection + refraction at one hit: full kernel with the HBM queue
         out.features = f;
     }
     out.closest_root = append_tlas(cinst, cbox, out);

@@ -38,7 +38,8 @@ enum Features : int {
     kFeatAnalytic = 1,     // balls / cuboids / cylinders / capsules / cones / planes exist
     kFeatMesh = 2,         // TriMesh nodes exist (BLAS traversal, ray/triangle)
     kFeatAlphaShadow = 4,  // some node may be non-opaque to shadow rays (per-node closest hit + colour filter)
-    kFeatAll = 7
+    kFeatDouble = 8,       // some node can spawn a reflection AND a refraction at one hit (second child -> HBM queue)
+    kFeatAll = 15
 };
 
 // ---------------------------------------------------------------- vector algebra (f64) -------
@@ -79,6 +80,7 @@ struct Cnt {
     unsigned node, tri, prim, hit, tex;     // instrumented builds only
     unsigned shadow, refl, refr;            // ray classes, always counted
     unsigned max_depth;                     // deepest trace depth reached by this lane
+    unsigned max_chain_nodes;               // instrumented: most AABB tests in one pixel's chain
 };
 
 // ---------------------------------------------------------------- traversal stack ------------
@@ -642,16 +644,28 @@ NR_DEV bool traverse(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, Hit&
     for (;;) {
         while (cur >= 0) {
             const float4* q = (const float4*)(S.nodes + cur);
-            float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-            int32_t left = __float_as_int(q3.x), right = __float_as_int(q3.y);
-            if (STATS) cnt.node += 2;
-            float tl = box_entry(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, rf, btf);
-            float tr = box_entry(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, rf, btf);
-            bool hl = tl >= 0.0f && left != kEmptyChild, hr = tr >= 0.0f && right != kEmptyChild;
-            if (hl && hr) {
-                if (tr < tl) { st.push(left); cur = right; }
-                else { st.push(right); cur = left; }
-            } else if (hl || hr) cur = hl ? left : right;
+            float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4], q5 = q[5];
+            int4 ch = ((const int4*)q)[6];
+            if (STATS) cnt.node += 4;
+            // child k: floats 6k .. 6k+5 of the node = (min.xyz, max.xyz)
+            float t0 = box_entry(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, rf, btf);
+            float t1 = box_entry(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, rf, btf);
+            float t2 = box_entry(q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, rf, btf);
+            float t3 = box_entry(q4.z, q4.w, q5.x, q5.y, q5.z, q5.w, rf, btf);
+            // misses (and absent children, whose inverted boxes always miss) sort last with key +inf
+            const float kMiss = __builtin_inff();
+            float k0 = (t0 >= 0.0f && ch.x != kEmptyChild) ? t0 : kMiss, k1 = (t1 >= 0.0f && ch.y != kEmptyChild) ? t1 : kMiss;
+            float k2 = (t2 >= 0.0f && ch.z != kEmptyChild) ? t2 : kMiss, k3 = (t3 >= 0.0f && ch.w != kEmptyChild) ? t3 : kMiss;
+            int32_t c0 = ch.x, c1 = ch.y, c2 = ch.z, c3 = ch.w;
+            // 5-comparator sorting network on (key, ref): ascending entry distance
+#define NR_CSWAP(ka, ca, kb, cb) { bool sw = kb < ka; float tk = sw ? kb : ka; kb = sw ? ka : kb; ka = tk; int32_t tc = sw ? cb : ca; cb = sw ? ca : cb; ca = tc; }
+            NR_CSWAP(k0, c0, k1, c1) NR_CSWAP(k2, c2, k3, c3) NR_CSWAP(k0, c0, k2, c2) NR_CSWAP(k1, c1, k3, c3) NR_CSWAP(k1, c1, k2, c2)
+#undef NR_CSWAP
+            // farthest first onto the stack, nearest becomes the next node
+            if (k3 < kMiss) st.push(c3);
+            if (k2 < kMiss) st.push(c2);
+            if (k1 < kMiss) st.push(c1);
+            if (k0 < kMiss) cur = c0;
             else cur = st.sp ? st.pop() : kEmptyChild;
         }
         if (cur == kEmptyChild) break;
@@ -862,11 +876,12 @@ NR_DEV void emit_rays(const QueueOut& qo, bool has, const RayState& r, uint32_t 
 }
 
 // One step of the trace recursion (Scene::trace, scene.rs:163-193): closest hit, shade, weight
-// algebra.  Returns this ray's own weighted contribution to its pixel and its continuation rays.
+// algebra.  Returns this ray's own weighted contribution to its pixel and REPLACES `ray` by its
+// continuation (has_next); a second continuation (only possible in kFeatDouble scenes) goes to `extra`.
 template <bool STATS, int FEAT>
-NR_DEV f3 shade_hit(const DScene& S, Stack& st, const RayState& ray, uint32_t depth, uint32_t max_depth,
-                    bool& has_refl, RayState& rr, bool& has_refr, RayState& rt, Cnt& cnt) {
-    has_refl = false; has_refr = false;
+NR_DEV f3 shade_hit(const DScene& S, Stack& st, RayState& ray, uint32_t depth, uint32_t max_depth,
+                    bool& has_next, bool& has_extra, RayState& extra, Cnt& cnt) {
+    has_next = false; has_extra = false;
     Hit hit; f3 nofilter = F3(1.0f, 1.0f, 1.0f);
     if (!traverse<false, STATS, FEAT>(S, st, ray.o, ray.d, kDblMax, hit, nofilter, cnt))
         return F3(S.background[0] * ray.weight, S.background[1] * ray.weight, S.background[2] * ray.weight);
@@ -883,24 +898,29 @@ NR_DEV f3 shade_hit(const DScene& S, Stack& st, const RayState& ray, uint32_t de
     float wa = alpha == 1.0f ? ray.weight : ray.weight * alpha; // scene.rs:183-190
     // own term: obj.rgb * (1 - mix), scene.rs:179-180 (applied even when reflection is gated off)
     float wo = wa * (1.0f - mix);
-    if (mix != 0.0f && ray.energy > 0.1f && may_recurse) { // trace_reflection, scene.rs:204-214
-        d3 nproj = is.n * dot(ray.d, is.n);
-        d3 rdir = ray.d - nproj * 2.0;
-        rr.o = pt + rdir * 0.001; rr.d = rdir; rr.refr = ray.refr; rr.energy = ray.energy - sn.refl_atenuation;
-        rr.weight = wa * mix; rr.key = rng_hash(ray.key, kSaltRefl); rr.pixel = ray.pixel;
-        has_refl = true; cnt.refl++;
-    }
-    if (alpha != 1.0f && may_recurse) { // trace_refraction, scene.rs:229-248
+    f3 contrib = F3(obj.x * wo, obj.y * wo, obj.z * wo);
+    bool do_refl = mix != 0.0f && ray.energy > 0.1f && may_recurse; // trace_reflection gate, scene.rs:204
+    bool do_refr = alpha != 1.0f && may_recurse;                    // trace_refraction gate, scene.rs:229
+    d3 dirn = is.n * dot(ray.d, is.n); // normal * dot(dir, normal): shared by both formulas
+    if (do_refr) { // scene.rs:229-248
         double n1, n2;
         if (ray.refr == 1.0) { n1 = 1.0; n2 = sn.refr_coeff; } else { n1 = sn.refr_coeff; n2 = 1.0; }
-        d3 dir_along_normal = is.n * dot(ray.d, is.n);
-        d3 tangent = ray.d - dir_along_normal;
-        d3 new_dir = normalize(dir_along_normal + tangent * (n2 / n1));
+        d3 tangent = ray.d - dirn;
+        d3 new_dir = normalize(dirn + tangent * (n2 / n1));
+        RayState rt;
         rt.o = pt + new_dir * 0.001; rt.d = new_dir; rt.refr = n2; rt.energy = ray.energy;
         rt.weight = ray.weight * (1.0f - alpha); rt.key = rng_hash(ray.key, kSaltRefr); rt.pixel = ray.pixel;
-        has_refr = true; cnt.refr++;
+        cnt.refr++;
+        if (do_refl) { if (FEAT & kFeatDouble) { extra = rt; has_extra = true; } }
+        else { ray = rt; has_next = true; return contrib; }
     }
-    return F3(obj.x * wo, obj.y * wo, obj.z * wo);
+    if (do_refl) { // scene.rs:204-214
+        d3 rdir = ray.d - dirn * 2.0;
+        ray.o = pt + rdir * 0.001; ray.d = rdir; ray.energy = ray.energy - sn.refl_atenuation;
+        ray.weight = wa * mix; ray.key = rng_hash(ray.key, kSaltRefl);
+        has_next = true; cnt.refl++;
+    }
+    return contrib;
 }
 
 // The recursion of Scene::trace unrolled into an iterative bounce loop.  A hit that spawns ONE
@@ -913,16 +933,15 @@ NR_DEV f3 trace_chain(const DScene& S, Stack& st, bool alive, RayState ray, uint
                       const QueueOut& qo, Cnt& cnt) {
     f3 sum = F3(0.0f, 0.0f, 0.0f);
     while (__ballot(alive) != 0ULL) { // wave-uniform
-        bool has_refl = false, has_refr = false;
-        RayState rr = ray, rt = ray;
+        bool has_extra = false;
+        RayState extra;
+        if (FEAT & kFeatDouble) extra = ray;
         if (alive) {
-            f3 c = shade_hit<STATS, FEAT>(S, st, ray, depth, max_depth, has_refl, rr, has_refr, rt, cnt);
+            f3 c = shade_hit<STATS, FEAT>(S, st, ray, depth, max_depth, alive, has_extra, extra, cnt);
             sum.x = sum.x + c.x; sum.y = sum.y + c.y; sum.z = sum.z + c.z;
             if (depth > cnt.max_depth) cnt.max_depth = depth;
         }
-        if (qo.capacity != 0) emit_rays(qo, has_refl && has_refr, rt, depth + 1); // uniform: capacity is a kernel argument
-        if (has_refl) ray = rr; else if (has_refr) ray = rt;
-        alive = has_refl || has_refr;
+        if (FEAT & kFeatDouble) emit_rays(qo, has_extra, extra, depth + 1);
         ++depth;
     }
     return sum;

@@ -41,10 +41,14 @@ class _MeshBuilder:
     def __init__(self):
         self.pts, self.uvs, self.groups, self.nv = [], [], [], 0
 
-    def add(self, material, p, uv, idx):
+    def add(self, material, p, uv, idx, join=False):
+        """join=True appends the faces to the previous group when it has the same material."""
         self.pts.append(p)
         self.uvs.append(uv)
-        self.groups.append((material, idx + self.nv))
+        if join and self.groups and self.groups[-1][0] == material:
+            self.groups[-1] = (material, np.concatenate([self.groups[-1][1], idx + self.nv]))
+        else:
+            self.groups.append((material, idx + self.nv))
         self.nv += len(p)
 
     def finish(self, scale):
@@ -146,10 +150,10 @@ def sponza_geometry(detail=1.0):
     d = lambda n: max(2, int(round(n * math.sqrt(detail))))  # noqa: E731
     L, Wd, Hh = 1800.0, 600.0, 1200.0  # half length, half width, height (OBJ units)
 
-    def quad(mat, o, eu, ev, nu, nv, uvs=(8.0, 8.0)):
+    def quad(mat, o, eu, ev, nu, nv, uvs=(8.0, 8.0), join=False):
         o, eu, ev = map(np.asarray, (o, eu, ev))
         p, uv, idx = _surface(lambda u, v: o + u[..., None] * eu + v[..., None] * ev, nu, nv, uvs)
-        mb.add(mat, p, uv, idx)
+        mb.add(mat, p, uv, idx, join)
 
     # floor (4 groups), ceiling, walls
     for k in range(4):
@@ -178,12 +182,12 @@ def sponza_geometry(detail=1.0):
                 p, uv, idx = _surface(col, d(42), d(27), (2, 4))
                 mb.add(col_mats[ci % 3], p, uv, idx)
                 # plinth + capital boxes (one group per column)
-                for y0, hh, w in ((level, 24.0, r * 1.5), (level + h - 24.0, 24.0, r * 1.4)):
+                for bi, (y0, hh, w) in enumerate(((level, 24.0, r * 1.5), (level + h - 24.0, 24.0, r * 1.4))):
                     for ax in range(4):
                         a0 = ax * math.pi / 2
                         c0 = np.array([x + w * math.cos(a0 + math.pi / 4) * math.sqrt(2), y0, s * 300.0 + w * math.sin(a0 + math.pi / 4) * math.sqrt(2)])
                         c1 = np.array([x + w * math.cos(a0 + 3 * math.pi / 4) * math.sqrt(2), y0, s * 300.0 + w * math.sin(a0 + 3 * math.pi / 4) * math.sqrt(2)])
-                        quad("plinth", c0, c1 - c0, (0, hh, 0), 2, 2, (1, 1))
+                        quad("plinth", c0, c1 - c0, (0, hh, 0), 2, 2, (1, 1), join=(bi + ax) > 0)
             for ci in range(len(xs) - 1):  # arches between neighbouring columns
                 x0, x1 = xs[ci], xs[ci + 1]
                 def arch(u, v, x0=x0, x1=x1, level=level, h=h, s=s):
@@ -229,7 +233,7 @@ def sponza_geometry(detail=1.0):
                 o = np.array([x, 90.0, s * 140.0])
                 eu = np.array([70.0 * math.cos(a), 50.0, 70.0 * math.sin(a)])
                 ev = np.array([-25.0 * math.sin(a), 60.0, 25.0 * math.cos(a)])
-                quad("leaf", o, eu, ev, d(4), d(4), (2, 2))
+                quad("leaf", o, eu, ev, d(4), d(4), (2, 2), join=lf > 0)  # one group per plant
     # flagpoles
     for k in range(6):
         x = -L + 500 + k * 520.0
