@@ -134,8 +134,8 @@ def main():
         t_primary = tst.kernel_ms_primary * 1e-3
         achieved = bytes_primary / t_primary / 1e9 if t_primary > 0 else 0.0
         traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_k_primary.json")
-        if os.path.exists(pmc_path):
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_k_primary.json")  # collected for the balls workload at 1920x1080
+        if os.path.exists(pmc_path) and args.scene == "balls" and (W, H) == (1920, 1080) and world == 1:
             try:
                 traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
             except Exception:
