@@ -75,22 +75,27 @@ def main():
     band = tiling.DEFAULT_BAND_ROWS
     p = tiling.tile_params(full, rank, world, band)
     rows = lib.nrays_tile_rows(C.byref(p))
-    tile = torch.zeros((rows, W, 3), dtype=torch.float32, device="cuda")
+    tiles = [torch.zeros((rows, W, 3), dtype=torch.float32, device="cuda") for _ in range(2)]
+    tile = tiles[0]
     handle = scene.device_handle()
     stream = torch.cuda.current_stream().cuda_stream
 
-    def render(instrumented=False):
+    def render(instrumented=False, into=None):
         fn = lib.nrays_render_device_instrumented if instrumented else lib.nrays_render_device
-        abi.check(fn(handle, C.byref(p), C.c_void_p(tile.data_ptr()), C.c_void_p(stream)))
+        abi.check(fn(handle, C.byref(p), C.c_void_p((tile if into is None else into).data_ptr()), C.c_void_p(stream)))
 
     frame = torch.empty((H, W, 3), dtype=torch.float32, device="cuda") if rank == 0 else None
 
+    # N > 1: render k+1 overlaps the RCCL gather of frame k (nrays_amd.tiling.FramePipeline); every frame is
+    # gathered and un-permuted on rank 0 before the timed region ends (flush()).
+    pipe = tiling.FramePipeline(rank, world, tiles, lambda t: render(into=t),
+                                lambda g, idx: tiling.untile_device(g, W, H, band, world, out=frame)) if world > 1 else None
+
     def step():
-        render()
-        if world > 1:
-            g = tiling.gather_tiles(tile, rank, world)
-            if rank == 0:
-                tiling.untile_device(g, W, H, band, world, out=frame)
+        if pipe is None:
+            render()
+        else:
+            pipe.step()
 
     # ---- untimed: instrumented frame -> ray counts and algorithmic bytes of the dominant kernel ----
     render(instrumented=True)
@@ -108,6 +113,8 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    if pipe is not None:
+        pipe.flush()
     nr.get_stats(scene)  # drains the event ring so that the averages below cover the timed steps only
     torch.cuda.synchronize()
     if world > 1:
@@ -116,6 +123,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    if pipe is not None:
+        pipe.flush()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

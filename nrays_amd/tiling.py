@@ -69,3 +69,53 @@ def untile_device(gathered, width, height, band_rows, world, out=None, stream=No
     abi.check(lib.nrays_untile_device(C.c_void_p(gathered.data_ptr()), C.c_void_p(out.data_ptr()), width, height,
                                       band_rows if world > 1 else height, world, C.c_void_p(stream)))
     return out
+
+
+class FramePipeline:
+    """Depth-1 software pipeline of the multi-GPU frame loop: while the gather of frame k is in flight
+    on the communication stream (RCCL), the render of frame k + 1 already runs on the compute stream;
+    rank 0 un-permutes frame k right after enqueuing render k + 1.  Two tile buffers and two gather
+    buffers alternate, so a buffer is never rewritten before its collective has consumed it.
+
+        render(tile_tensor)            enqueue the rank's tile render into `tile_tensor`
+        untile(gathered, frame_index)  rank 0 only: consume the gathered (world, rows, W, 3) tensor
+    """
+
+    def __init__(self, rank, world, tiles, render, untile, group=None):
+        import torch
+        assert len(tiles) == 2
+        self.rank, self.world, self.tiles, self.render, self.untile, self.group = rank, world, tiles, render, untile, group
+        self.gathered = None
+        if world > 1 and rank == 0:
+            self.gathered = [torch.empty((world,) + tuple(tiles[0].shape), dtype=tiles[0].dtype, device=tiles[0].device)
+                             for _ in range(2)]
+        self.pending = None  # (work, slot, frame index)
+        self.k = 0
+
+    def _finish(self):
+        if self.pending is None:
+            return
+        work, slot, idx = self.pending
+        if work is not None:
+            work.wait()  # the compute stream waits for the collective; no host block for NCCL
+        if self.rank == 0:
+            self.untile(self.gathered[slot] if self.world > 1 else self.tiles[slot].unsqueeze(0), idx)
+        self.pending = None
+
+    def step(self):
+        import torch.distributed as dist
+        slot = self.k & 1
+        self.render(self.tiles[slot])
+        self._finish()  # frame k - 1: its gather overlapped the render just enqueued
+        work = None
+        if self.world > 1:
+            if self.rank == 0:
+                work = dist.gather(self.tiles[slot], gather_list=list(self.gathered[slot].unbind(0)), dst=0,
+                                   group=self.group, async_op=True)
+            else:
+                work = dist.gather(self.tiles[slot], gather_list=None, dst=0, group=self.group, async_op=True)
+        self.pending = (work, slot, self.k)
+        self.k += 1
+
+    def flush(self):
+        self._finish()

@@ -66,3 +66,44 @@ def test_two_ranks_gather_a_bit_identical_frame(tmp_path):
     out = str(tmp_path / "err.npy")
     mp.spawn(_worker, args=(2, port, 40, 37, 8, out), nprocs=2, join=True)
     assert np.load(out)[0] == 0.0
+
+
+def _pipeline_worker(rank, world, port, result_path):
+    """FramePipeline with a fake renderer (frame k, rank r -> constant tile k*10 + r): every frame must
+    reach rank 0 intact and in order although render k+1 is enqueued before gather k is consumed."""
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    tiles = [torch.zeros((4, 5, 3)), torch.zeros((4, 5, 3))]
+    state = {"k": 0, "seen": []}
+
+    def render(t):
+        t.fill_(state["k"] * 10 + rank)
+        state["k"] += 1
+
+    def untile(g, idx):
+        state["seen"].append((idx, [float(g[r].mean()) for r in range(world)], bool((g[0] == g[0, 0, 0, 0]).all())))
+
+    pipe = tiling.FramePipeline(rank, world, tiles, render, untile)
+    for _ in range(5):
+        pipe.step()
+    pipe.flush()
+    if rank == 0:
+        ok = len(state["seen"]) == 5 and all(idx == k and vals == [k * 10.0 + r for r in range(world)] and uniform
+                                              for k, (idx, vals, uniform) in enumerate(state["seen"]))
+        np.save(result_path, np.array([1.0 if ok else 0.0]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_frame_pipeline_two_ranks(tmp_path):
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "ok.npy")
+    mp.spawn(_pipeline_worker, args=(2, port, out), nprocs=2, join=True)
+    assert np.load(out)[0] == 1.0
