@@ -270,6 +270,7 @@ struct NraysScene {
     // stream; nrays_get_stats averages the frames recorded since its previous call.
     static constexpr int kRing = 256;
     hipEvent_t ev_begin[kRing] = {}, ev_pbegin[kRing] = {}, ev_pend[kRing] = {}, ev_end[kRing] = {};
+    bool single_launch[kRing] = {};
     uint64_t frames_recorded = 0, frames_reported = 0;
     DeviceCounters* d_counters_primary = nullptr; // snapshot taken right after the primary kernel
     hipStream_t last_stream = nullptr;
@@ -354,7 +355,8 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
     if (npix_local >= (1ull << 31)) return fail(NRAYS_ERR_UNSUPPORTED, "tile too large");
 
     // sample batching keeps the number of primary rays (and hence continuation rays) per launch bounded
-    const uint64_t kMaxPrimaryPerLaunch = 32ull << 20;
+    uint64_t kMaxPrimaryPerLaunch = 32ull << 20;
+    if (const char* e = getenv("NRAYS_MAX_PRIMARY")) kMaxPrimaryPerLaunch = (uint64_t)std::max(1ll, atoll(e)); // tests: force sample batching
     uint32_t batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(p->ray_per_pixel, kMaxPrimaryPerLaunch / std::max<uint64_t>(1, npix_local)));
 
     // Continuation rays stay in registers (trace_chain); the HBM queue is only needed when one hit can
@@ -385,7 +387,9 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
     const uint32_t grid_primary = std::min<uint32_t>(((ntiles + 7u) / 8u) * 8u, 256u * (uint32_t)waves_per_simd(instrumented ? kFeatAll : sc->features));
 
     const int slot = (int)(sc->frames_recorded % NraysScene::kRing);
-    HIP_TRY(hipEventRecord(sc->ev_begin[slot], stream));
+    // events: [pbegin .. pend] brackets the first primary launch; the frame spans [pbegin .. end], and
+    // `end` is only recorded separately when something follows the primary kernel
+    const bool single_launch = !queued && p->ray_per_pixel <= batch && p->ray_per_pixel == 1;
     sc->d_counters = sc->d_counters_set[sc->frame_index & 1];
     DeviceCounters* next_ctr = sc->d_counters_set[(sc->frame_index + 1) & 1];
     sc->frame_index++;
@@ -429,7 +433,8 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
         hipLaunchKernelGGL(k_resolve, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_out, n, (float)p->ray_per_pixel);
         HIP_TRY(hipGetLastError());
     }
-    HIP_TRY(hipEventRecord(sc->ev_end[slot], stream));
+    if (!single_launch) HIP_TRY(hipEventRecord(sc->ev_end[slot], stream));
+    sc->single_launch[slot] = single_launch;
     sc->frames_recorded++;
     sc->last_stream = stream; sc->have_last = true;
     // owned rows only (padding rows of the last band carry no rays)
@@ -573,7 +578,7 @@ int nrays_get_stats(NraysScene* sc, NraysStats* out) {
         int k = (int)(f % NraysScene::kRing);
         float ms_p = 0.f, ms_t = 0.f;
         if (hipEventElapsedTime(&ms_p, sc->ev_pbegin[k], sc->ev_pend[k]) == hipSuccess &&
-            hipEventElapsedTime(&ms_t, sc->ev_begin[k], sc->ev_end[k]) == hipSuccess) { sum_p += ms_p; sum_t += ms_t; ++n; }
+            hipEventElapsedTime(&ms_t, sc->ev_pbegin[k], sc->single_launch[k] ? sc->ev_pend[k] : sc->ev_end[k]) == hipSuccess) { sum_p += ms_p; sum_t += ms_t; ++n; }
     }
     sc->frames_reported = sc->frames_recorded;
     if (n) { out->kernel_ms_primary = sum_p / (double)n; out->kernel_ms_total = sum_t / (double)n; }

@@ -200,3 +200,25 @@ def test_double_branching_uses_the_compacted_queue(gpu):
     cam = dict(eye=(0.0, 2.0, -7.0), at=(0.0, 0.0, 0.0), fovy=45.0)
     _, _, st, _ = compare(sc, cam, 160, 120)
     assert st.rays_reflection > 0 and st.rays_refraction > 0 and st.generations >= 3
+
+
+def test_sample_batching_multiple_primary_launches(gpu, monkeypatch):
+    """ray_per_pixel > 1 with the per-launch primary-ray budget forced low: several k_primary launches
+    accumulate into the frame, then k_resolve divides by ray_per_pixel (scene.rs:91-94)."""
+    monkeypatch.setenv("NRAYS_MAX_PRIMARY", str(96 * 72 * 2))  # 2 samples per launch -> 3 launches for spp 5
+    sc, cam = su.primitives_scene(light_radius=0.1, nsample=10)
+    _, _, st, _ = compare(sc, cam, 96, 72, spp=5, window=1.0, seed=3)
+    assert st.rays_primary == 96 * 72 * 5
+    sc2, cam2 = su.mesh_scene()
+    compare(sc2, cam2, 96, 72, spp=5, window=0.7, seed=9)
+
+
+def test_area_lights_on_meshes_and_eight_lights(gpu):
+    from tests import standins
+    sc, cam = standins.sponza_scene(detail=0.1, n_lights=8)
+    compare(sc, cam, 96, 54, threads=32)
+    sc, cam = su.mesh_scene(n_lights=2)
+    sc._lights = [nr.Light(l.pos, 0.3, 4, l.color) for l in sc._lights]
+    sc._descriptor = None
+    _, _, st, _ = compare(sc, cam, 80, 60, seed=5)
+    assert st.rays_shadow > 4 * 2 * 80 * 60 * 0.3
