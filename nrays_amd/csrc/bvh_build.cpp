@@ -170,10 +170,10 @@ struct Collapser {
         BvhNode& n = out[me];
         for (int k = 0; k < 4; ++k) {
             if (k < (int)slots.size()) {
-                for (int a = 0; a < 3; ++a) { n.box[k][a] = slots[k].mn[a]; n.box[k][3 + a] = slots[k].mx[a]; }
+                for (int a = 0; a < 3; ++a) { n.mn[a][k] = slots[k].mn[a]; n.mx[a][k] = slots[k].mx[a]; }
                 n.child[k] = refs[k];
             } else {
-                for (int a = 0; a < 3; ++a) { n.box[k][a] = std::numeric_limits<float>::infinity(); n.box[k][3 + a] = -std::numeric_limits<float>::infinity(); }
+                for (int a = 0; a < 3; ++a) { n.mn[a][k] = std::numeric_limits<float>::infinity(); n.mx[a][k] = -std::numeric_limits<float>::infinity(); }
                 n.child[k] = kEmptyChild;
             }
             n.pad[k] = 0;

@@ -16,7 +16,8 @@ namespace nrays {
 // count - 1 for triangle leaves (BLAS) and LeafBits for TLAS leaves (first = instance index).  An
 // absent child has an inverted box (min = +inf, max = -inf) and child = kEmptyChild.
 struct BvhNode {
-    float box[4][6]; // child k: min.xyz, max.xyz
+    float mn[3][4]; // mn[axis][child]: one dwordx4 = the same coordinate of all four children, so the
+    float mx[3][4]; // slab arithmetic runs two children per packed-f32 instruction (v_pk_add/mul_f32)
     int32_t child[4];
     uint32_t pad[4];
 };

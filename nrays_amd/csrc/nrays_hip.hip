@@ -70,6 +70,16 @@ __device__ __forceinline__ void flush_counters(DeviceCounters* ctr, const Cnt& c
         if (stats) { unsigned oc = __shfl_down(mc, off); mc = oc > mc ? oc : mc; }
         if (stats) { nd += __shfl_down(nd, off); tr += __shfl_down(tr, off); pr += __shfl_down(pr, off); ht += __shfl_down(ht, off); tx += __shfl_down(tx, off); }
     }
+#ifdef NR_PHASE_TIMING
+    unsigned pn = c.cyc_node, pl = c.cyc_leaf; // accumulators only advance in active lanes: take the max over the wave
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { unsigned a = __shfl_down(pn, off), b = __shfl_down(pl, off); pn = a > pn ? a : pn; pl = b > pl ? b : pl; }
+    if (__lane_id() == 0) {
+        atomicAdd(&ctr->node_tests, (unsigned long long)pn);   // tuning builds reuse the instrumented fields:
+        atomicAdd(&ctr->tri_tests, (unsigned long long)pl);    // node_tests = cycles in node loops, tri_tests = leaf phases,
+        atomicAdd(&ctr->prim_tests, (unsigned long long)c.cyc_other);  // prim_tests = whole-wave cycles
+    }
+#endif
     if (__lane_id() == 0) {
         if (sh) atomicAdd(&ctr->rays_shadow, (unsigned long long)sh);
         if (rl) atomicAdd(&ctr->rays_reflection, (unsigned long long)rl);
@@ -105,6 +115,10 @@ __global__ void __launch_bounds__(kBlock, waves_per_simd(FEAT)) k_primary(DScene
     st.spill = spill ? spill + (size_t)blockIdx.x * kBlock + threadIdx.x : nullptr;
     st.sp = 0;
     Cnt cnt; cnt.node = cnt.tri = cnt.prim = cnt.hit = cnt.tex = cnt.shadow = cnt.refl = cnt.refr = cnt.max_depth = cnt.max_chain_nodes = 0;
+#ifdef NR_PHASE_TIMING
+    cnt.cyc_node = cnt.cyc_leaf = cnt.cyc_other = 0;
+    unsigned long long twave = __builtin_readcyclecounter();
+#endif
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t nwt = tiles_x * tiles_y * 4u; // wave tiles: 4 per 16x16 block
@@ -175,6 +189,9 @@ __global__ void __launch_bounds__(kBlock, waves_per_simd(FEAT)) k_primary(DScene
       }
       if (grab == 1u) pending = issue_grab(work_counters, victim, grab);
     }
+#ifdef NR_PHASE_TIMING
+    cnt.cyc_other = (unsigned)(__builtin_readcyclecounter() - twave);
+#endif
     flush_counters(ctr, cnt, STATS);
 }
 
@@ -189,6 +206,9 @@ __global__ void __launch_bounds__(kBlock, NRAYS_WAVES_PER_SIMD) k_bounce(DScene 
     st.spill = spill ? spill + (size_t)blockIdx.x * kBlock + threadIdx.x : nullptr;
     st.sp = 0;
     Cnt cnt; cnt.node = cnt.tri = cnt.prim = cnt.hit = cnt.tex = cnt.shadow = cnt.refl = cnt.refr = cnt.max_depth = cnt.max_chain_nodes = 0;
+#ifdef NR_PHASE_TIMING
+    cnt.cyc_node = cnt.cyc_leaf = cnt.cyc_other = 0;
+#endif
     uint32_t n = *count_in;
     if (n > capacity) n = capacity;
     for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) { // block-uniform trip count

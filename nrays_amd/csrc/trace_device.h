@@ -76,11 +76,23 @@ NR_DEV double rng_u01(unsigned long long key, unsigned long long dim) {
 constexpr unsigned long long kSaltPath = 2ULL, kSaltRefl = 0x100ULL, kSaltRefr = 0x101ULL, kSaltLight = 0x200ULL;
 
 // ---------------------------------------------------------------- counters -------------------
+#ifdef NR_PHASE_TIMING
+// Tuning builds only (tools/kbench.py --libs ...): wave-level s_memtime attribution of the cycles of a
+// wave to traversal phases; lane 0 accumulates, flush_counters sums over waves.
+#define NR_TIC(var) unsigned long long var = __builtin_readcyclecounter()
+#define NR_TOC(cntfield, var) { unsigned long long now_ = __builtin_readcyclecounter(); cnt.cntfield += (unsigned)(now_ - var); var = now_; }
+#else
+#define NR_TIC(var)
+#define NR_TOC(cntfield, var)
+#endif
 struct Cnt {
     unsigned node, tri, prim, hit, tex;     // instrumented builds only
     unsigned shadow, refl, refr;            // ray classes, always counted
     unsigned max_depth;                     // deepest trace depth reached by this lane
     unsigned max_chain_nodes;               // instrumented: most AABB tests in one pixel's chain
+#ifdef NR_PHASE_TIMING
+    unsigned cyc_node, cyc_leaf, cyc_other; // per-wave cycles (valid in lane 0)
+#endif
 };
 
 // ---------------------------------------------------------------- traversal stack ------------
@@ -528,6 +540,33 @@ NR_DEV float box_entry(float mnx, float mny, float mnz, float mxx, float mxy, fl
     return (tn * 0.9999995f <= tf * 1.0000005f) ? tn : -1.0f;
 }
 
+// Four boxes at once (the SoA node layout of device_types.h): same arithmetic and margins as
+// box_entry, two children per packed-f32 instruction for the subtract / multiply / margin steps.
+typedef float f2 __attribute__((ext_vector_type(2)));
+NR_DEV void slab2(f2 mn, f2 mx, float o, float inv, float e, f2& tn, f2& tf) {
+    f2 a = (mn - o) * inv, b = (mx - o) * inv;
+    tn = __builtin_elementwise_min(a, b) - e;
+    tf = __builtin_elementwise_max(a, b) + e;
+}
+NR_DEV void box_entry4(float4 mnx, float4 mny, float4 mnz, float4 mxx, float4 mxy, float4 mxz, const RayF& r, float tbest,
+                       float& t0, float& t1, float& t2, float& t3) {
+    f2 xn0, xf0, xn1, xf1, yn0, yf0, yn1, yf1, zn0, zf0, zn1, zf1;
+    slab2(f2{mnx.x, mnx.y}, f2{mxx.x, mxx.y}, r.ox, r.ix, r.ex, xn0, xf0);
+    slab2(f2{mnx.z, mnx.w}, f2{mxx.z, mxx.w}, r.ox, r.ix, r.ex, xn1, xf1);
+    slab2(f2{mny.x, mny.y}, f2{mxy.x, mxy.y}, r.oy, r.iy, r.ey, yn0, yf0);
+    slab2(f2{mny.z, mny.w}, f2{mxy.z, mxy.w}, r.oy, r.iy, r.ey, yn1, yf1);
+    slab2(f2{mnz.x, mnz.y}, f2{mxz.x, mxz.y}, r.oz, r.iz, r.ez, zn0, zf0);
+    slab2(f2{mnz.z, mnz.w}, f2{mxz.z, mxz.w}, r.oz, r.iz, r.ez, zn1, zf1);
+    float n0 = fmaxf(fmaxf(xn0.x, yn0.x), fmaxf(zn0.x, 0.0f)), f0 = fminf(fminf(xf0.x, yf0.x), fminf(zf0.x, tbest));
+    float n1 = fmaxf(fmaxf(xn0.y, yn0.y), fmaxf(zn0.y, 0.0f)), f1 = fminf(fminf(xf0.y, yf0.y), fminf(zf0.y, tbest));
+    float n2 = fmaxf(fmaxf(xn1.x, yn1.x), fmaxf(zn1.x, 0.0f)), f2_ = fminf(fminf(xf1.x, yf1.x), fminf(zf1.x, tbest));
+    float n3 = fmaxf(fmaxf(xn1.y, yn1.y), fmaxf(zn1.y, 0.0f)), f3 = fminf(fminf(xf1.y, yf1.y), fminf(zf1.y, tbest));
+    t0 = (n0 * 0.9999995f <= f0 * 1.0000005f) ? n0 : -1.0f;
+    t1 = (n1 * 0.9999995f <= f1 * 1.0000005f) ? n1 : -1.0f;
+    t2 = (n2 * 0.9999995f <= f2_ * 1.0000005f) ? n2 : -1.0f;
+    t3 = (n3 * 0.9999995f <= f3 * 1.0000005f) ? n3 : -1.0f;
+}
+
 // ncollide ray_aabb (AABB::toi_with_ray, solid = true; SURVEY B-3) as a predicate, in f64 and in the
 // reference's operation order.  The reference only casts a node / tests a triangle whose AABB this
 // test accepts (src/scene.rs:276 and the TriMesh BVT), so it is applied to every ACCEPTED hit; the
@@ -561,15 +600,16 @@ NR_DEV bool tri_aabb_pass(d3 a, d3 b, d3 c, d3 o, d3 d) {
 }
 
 // Reconstructs the full intersection record of a finished closest-hit query.
-template <bool SHADOW, int FEAT>
-NR_DEV void resolve_hit(const DScene& S, d3 o, d3 d, const Hit& h, Isect& out, uint32_t& node_id) {
+// Returns whether the hit passes the reference's AABB gates (only evaluated when CHECK is set).
+template <bool SHADOW, int FEAT, bool CHECK = false>
+NR_DEV bool resolve_hit(const DScene& S, d3 o, d3 d, const Hit& h, Isect& out, uint32_t& node_id) {
     const Instance& in = (SHADOW ? S.shadow_instances : S.instances)[h.inst];
     if ((FEAT & kFeatAnalytic) && (!(FEAT & kFeatMesh) || in.kind != NRAYS_SHAPE_TRIMESH)) {
         cast_analytic(in, o, d, out);
         node_id = (uint32_t)in.node_id;
-        return;
+        return !CHECK || in.kind == NRAYS_SHAPE_PLANE || node_aabb_pass(S, node_id, o, d);
     }
-    if (!(FEAT & kFeatMesh)) { node_id = 0; out.toi = 0.0; out.n = D3(0, 0, 0); out.u = out.v = 0.0; out.has_uv = false; return; }
+    if (!(FEAT & kFeatMesh)) { node_id = 0; out.toi = 0.0; out.n = D3(0, 0, 0); out.u = out.v = 0.0; out.has_uv = false; return true; }
     Xform m; load_xform(in, m);
     d3 lo = o, ld = d;
     if (!(in.flags & kInstIdentityRot)) { lo = inv_rot(m, o - m.t); ld = inv_rot(m, d); }
@@ -588,6 +628,7 @@ NR_DEV void resolve_hit(const DScene& S, d3 o, d3 d, const Hit& h, Isect& out, u
         out.u = (double)uv.uv[0] * bary[0] + (double)uv.uv[2] * bary[1] + (double)uv.uv[4] * bary[2];
         out.v = (double)uv.uv[1] * bary[0] + (double)uv.uv[3] * bary[1] + (double)uv.uv[5] * bary[2];
     }
+    return !CHECK || (tri_aabb_pass(a, b, c, lo, ld) && node_aabb_pass(S, node_id, o, d));
 }
 
 // Shadow-ray bookkeeping of one node-closest hit (scene.rs:313-338): returns true if it blocks.
@@ -612,8 +653,14 @@ NR_DEV bool shadow_node_hit(const DScene& S, uint32_t node_id, const Isect& is, 
 //   SHADOW == true : TransparentShadowsRayTOICostFn — returns true if an opaque node-closest hit
 //                    lies within `tlimit`; otherwise `filter` holds the product of the transparent
 //                    node-closest hits' colour filters.
+// GATED: apply the reference's exact AABB gates (node world AABB, triangle AABB; 6 f64 divisions) to every
+// candidate.  Shadow rays always gate (a hit decides immediately).  Closest-hit rays run UNGATED and the
+// caller verifies only the winner: the gated candidate set is a subset of the ungated one, so if the
+// ungated minimum passes the gates it is also the gated minimum; if it fails (knife-edge rays only) the
+// caller re-runs the same traversal with gated_closest = true.
 template <bool SHADOW, bool STATS, int FEAT>
-NR_DEV bool traverse(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, Hit& hit, f3& filter, Cnt& cnt) {
+NR_DEV bool traverse(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, Hit& hit, f3& filter, Cnt& cnt, bool gated_closest = false) {
+    const bool GATED = SHADOW || gated_closest;
     constexpr bool kAnalytic = (FEAT & kFeatAnalytic) != 0, kMesh = (FEAT & kFeatMesh) != 0;
     constexpr bool kAlpha = (FEAT & kFeatAlphaShadow) != 0; // shadow mode: otherwise every hit within tlimit blocks
     const Instance* insts = SHADOW ? S.shadow_instances : S.instances;
@@ -641,17 +688,16 @@ NR_DEV bool traverse(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, Hit&
     // "while-while" traversal: the wave first runs internal-node steps only (one 64-byte fetch and two
     // f32 box tests per step) until every lane holds a leaf or is done, then runs the leaf code, instead
     // of serialising node / instance / triangle / sentinel code paths in every iteration.
+    NR_TIC(tphase);
     for (;;) {
+        NR_TOC(cyc_leaf, tphase);
         while (cur >= 0) {
             const float4* q = (const float4*)(S.nodes + cur);
-            float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4], q5 = q[5];
+            float4 mnx = q[0], mny = q[1], mnz = q[2], mxx = q[3], mxy = q[4], mxz = q[5];
             int4 ch = ((const int4*)q)[6];
             if (STATS) cnt.node += 4;
-            // child k: floats 6k .. 6k+5 of the node = (min.xyz, max.xyz)
-            float t0 = box_entry(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, rf, btf);
-            float t1 = box_entry(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, rf, btf);
-            float t2 = box_entry(q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, rf, btf);
-            float t3 = box_entry(q4.z, q4.w, q5.x, q5.y, q5.z, q5.w, rf, btf);
+            float t0, t1, t2, t3;
+            box_entry4(mnx, mny, mnz, mxx, mxy, mxz, rf, btf, t0, t1, t2, t3);
             // misses (and absent children, whose inverted boxes always miss) sort last with key +inf
             const float kMiss = __builtin_inff();
             float k0 = (t0 >= 0.0f && ch.x != kEmptyChild) ? t0 : kMiss, k1 = (t1 >= 0.0f && ch.y != kEmptyChild) ? t1 : kMiss;
@@ -668,6 +714,7 @@ NR_DEV bool traverse(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, Hit&
             if (k0 < kMiss) cur = c0;
             else cur = st.sp ? st.pop() : kEmptyChild;
         }
+        NR_TOC(cyc_node, tphase);
         if (cur == kEmptyChild) break;
         if (kMesh && cur == kSentinel) { // the BLAS of `cur_inst` is exhausted: back to world space
             in_blas = false;
@@ -695,8 +742,8 @@ NR_DEV bool traverse(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, Hit&
                 if (STATS) cnt.tri++;
                 double toi;
                 d3 va = D3(t0.x, t0.y, t0.z), vb = D3(t1.x, t1.y, t1.z), vc = D3(t2.x, t2.y, t2.z);
-                if (cast_triangle(va, vb, vc, co, cd, toi, nullptr, nullptr) && tri_aabb_pass(va, vb, vc, co, cd) &&
-                    node_aabb_pass(S, __float_as_uint(t0.w), o, d)) {
+                if (cast_triangle(va, vb, vc, co, cd, toi, nullptr, nullptr) &&
+                    (!GATED || (tri_aabb_pass(va, vb, vc, co, cd) && node_aabb_pass(S, __float_as_uint(t0.w), o, d)))) {
                     if (SHADOW && (!kAlpha || (cur_flags & kInstAnyHit))) { if (toi <= tlimit) return true; }
                     else {
                         unsigned long long key = SHADOW ? (unsigned long long)__float_as_uint(t1.w)
@@ -729,7 +776,7 @@ NR_DEV bool traverse(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, Hit&
             const Instance& in = insts[first];
             if (STATS) cnt.prim++;
             Isect is;
-            if (cast_analytic(in, o, d, is) && (in.kind == NRAYS_SHAPE_PLANE || node_aabb_pass(S, (uint32_t)in.node_id, o, d))) {
+            if (cast_analytic(in, o, d, is) && (!GATED || in.kind == NRAYS_SHAPE_PLANE || node_aabb_pass(S, (uint32_t)in.node_id, o, d))) {
                 if (SHADOW) {
                     if (is.toi <= tlimit) {
                         if (!kAlpha) return true;
@@ -883,10 +930,14 @@ NR_DEV f3 shade_hit(const DScene& S, Stack& st, RayState& ray, uint32_t depth, u
                     bool& has_next, bool& has_extra, RayState& extra, Cnt& cnt) {
     has_next = false; has_extra = false;
     Hit hit; f3 nofilter = F3(1.0f, 1.0f, 1.0f);
-    if (!traverse<false, STATS, FEAT>(S, st, ray.o, ray.d, kDblMax, hit, nofilter, cnt))
-        return F3(S.background[0] * ray.weight, S.background[1] * ray.weight, S.background[2] * ray.weight);
     Isect is; uint32_t node_id;
-    resolve_hit<false, FEAT>(S, ray.o, ray.d, hit, is, node_id);
+    bool gated = false;
+    for (;;) { // second iteration only when the ungated winner fails the reference's AABB gates (knife-edge rays)
+        if (!traverse<false, STATS, FEAT>(S, st, ray.o, ray.d, kDblMax, hit, nofilter, cnt, gated))
+            return F3(S.background[0] * ray.weight, S.background[1] * ray.weight, S.background[2] * ray.weight);
+        if (resolve_hit<false, FEAT, true>(S, ray.o, ray.d, hit, is, node_id) || gated) break;
+        gated = true;
+    }
     is.toi = hit.t;
     if (STATS) cnt.hit++;
     const NodeRec& sn = S.node_recs[node_id];
