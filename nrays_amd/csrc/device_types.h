@@ -94,6 +94,25 @@ struct TextureRec { // src/texture2d.rs:62-66
     const void* texels;
 };
 
+// Everything shading needs about a SceneNode in ONE record (scene_node.rs:8-19 + its PhongMaterial,
+// phong_material.rs:9-16, + the two texture descriptors, texture2d.rs:62-66): after a hit the chain of
+// dependent fetches is triangle -> ShadeRec -> texels instead of node -> material -> texture -> texels.
+struct ShadeTex {
+    const void* texels; // null = no texture
+    uint32_t width, height;
+    uint32_t mode;      // format | interp << 8 | overflow << 16
+    uint32_t pad;
+};
+struct ShadeRec {
+    float refl_mix, refl_atenuation, alpha;
+    uint32_t flags;     // bit 0: the shape / mesh carries uvs; bits 8..15: NraysMaterialKind
+    double refr_coeff;
+    float ka[3], kd[3], ks[3], shininess;
+    ShadeTex tex, alpha_tex;
+    uint32_t pad[2];
+};
+static_assert(sizeof(ShadeRec) == 120 || sizeof(ShadeRec) == 128, "ShadeRec layout");
+
 struct LightRec { // src/light.rs:8-13
     double pos[3];
     double radius;
@@ -137,11 +156,9 @@ struct DScene {
     const Instance* shadow_instances; // shadow TLAS leaves (+ planes at the end)
     const InstLink* links;            // parallel to instances
     const InstLink* shadow_links;     // parallel to shadow_instances
-    const NodeRec* node_recs;
+    const ShadeRec* shade;            // one per scene node
     const double* node_aabbs;         // 6 f64 per scene node: world AABB exactly as the reference computes
                                       // geometry.bounding_volume(&transform) (scene_node.rs:41); gates accepted hits
-    const MaterialRec* materials;
-    const TextureRec* textures;
     const LightRec* lights;
     const int32_t* planes;        // indices into `instances` of planes (infinite AABB: tested linearly)
     const int32_t* shadow_planes; // indices into `shadow_instances` of the same planes
@@ -161,7 +178,6 @@ struct DRender {
     uint32_t band_rows, band_owner, band_owners;
     uint32_t first_batch;        // 1: store into out, 0: add
     uint32_t use_rng;            // 0 when no random number can be consumed (window == 0, no area light)
-    uint32_t reverse_tiles;      // scheduling order of the wave tiles (speed only)
     double window_width;
     double eye[3];
     double m[16];                // (P V)^-1 column-major

@@ -155,8 +155,7 @@ __global__ void __launch_bounds__(kBlock, waves_per_simd(FEAT)) k_primary(DScene
           last = first + grab < end ? first + grab : end;
           if (prefetch) pending = issue_grab(work_counters, victim, grab); // issued now, consumed after the tiles below
       }
-      for (uint32_t wt0 = first; wt0 < last; ++wt0) {
-        uint32_t wt = R.reverse_tiles ? nwt - 1u - wt0 : wt0;
+      for (uint32_t wt = first; wt < last; ++wt) {
         uint32_t tile = wt >> 2, sub = wt & 3u;
         uint32_t tx = tile % tiles_x, ty = tile / tiles_x;
         uint32_t lx = ((sub & 1u) << 3) | (lane & 7u), ly = ((sub >> 1) << 3) | (lane >> 3);
@@ -403,7 +402,7 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
     const uint32_t tiles_x = (p->width + kTile - 1) / kTile, tiles_y = (rows + kTile - 1) / kTile;
     const uint32_t ntiles = tiles_x * tiles_y;
     uint32_t grab = (sc->features & kFeatMesh) ? 1u : 0u; // 0 = static wave-interleaved assignment
-    if (const char* e = getenv("NRAYS_GRAB")) grab = (uint32_t)std::max(0, atoi(e)); // tuning override (tools/kbench.py)
+    if (const char* e = getenv("NRAYS_GRAB")) grab = (uint32_t)std::max(0, atoi(e)); // scheduling A/B override (tools/kbench.py); pixels do not depend on it
     const uint32_t grid_primary = std::min<uint32_t>(((ntiles + 7u) / 8u) * 8u, 256u * (uint32_t)waves_per_simd(instrumented ? kFeatAll : sc->features));
 
     const int slot = (int)(sc->frames_recorded % NraysScene::kRing);
@@ -414,8 +413,6 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
     DeviceCounters* next_ctr = sc->d_counters_set[(sc->frame_index + 1) & 1];
     sc->frame_index++;
     R.use_rng = (p->window_width != 0.0 || sc->host.any_area_light) ? 1u : 0u;
-    R.reverse_tiles = 0;
-    if (const char* e = getenv("NRAYS_REVERSE")) R.reverse_tiles = (uint32_t)atoi(e);
     bool first_primary = true;
     for (uint32_t s0 = 0; s0 < p->ray_per_pixel; s0 += batch) {
         R.sample_begin = s0; R.sample_end = std::min<uint32_t>(p->ray_per_pixel, s0 + batch);
@@ -496,9 +493,9 @@ int nrays_scene_create(const NraysSceneDesc* desc, NraysScene** out_scene) {
     if ((rc = upload(sc, h.shadow_instances, &sc->d.shadow_instances)) != NRAYS_OK) return bail(rc);
     if ((rc = upload(sc, h.links, &sc->d.links)) != NRAYS_OK) return bail(rc);
     if ((rc = upload(sc, h.shadow_links, &sc->d.shadow_links)) != NRAYS_OK) return bail(rc);
-    if ((rc = upload(sc, h.node_recs, &sc->d.node_recs)) != NRAYS_OK) return bail(rc);
+
     if ((rc = upload(sc, h.node_aabbs, &sc->d.node_aabbs)) != NRAYS_OK) return bail(rc);
-    if ((rc = upload(sc, h.materials, &sc->d.materials)) != NRAYS_OK) return bail(rc);
+
     if ((rc = upload(sc, h.lights, &sc->d.lights)) != NRAYS_OK) return bail(rc);
     if ((rc = upload(sc, h.planes, &sc->d.planes)) != NRAYS_OK) return bail(rc);
     if ((rc = upload(sc, h.shadow_planes, &sc->d.shadow_planes)) != NRAYS_OK) return bail(rc);
@@ -511,7 +508,11 @@ int nrays_scene_create(const NraysSceneDesc* desc, NraysScene** out_scene) {
         TextureRec r = t.rec; r.texels = p; trecs.push_back(r);
         std::vector<uint8_t>().swap(t.bytes);
     }
-    if ((rc = upload(sc, trecs, &sc->d.textures)) != NRAYS_OK) return bail(rc);
+    for (size_t i = 0; i < h.shade.size(); ++i) { // patch the device texel pointers into the per-node shading records
+        if (h.shade_tex[i] >= 0) h.shade[i].tex.texels = trecs[h.shade_tex[i]].texels;
+        if (h.shade_alpha_tex[i] >= 0) h.shade[i].alpha_tex.texels = trecs[h.shade_alpha_tex[i]].texels;
+    }
+    if ((rc = upload(sc, h.shade, &sc->d.shade)) != NRAYS_OK) return bail(rc);
     sc->d.closest_root = h.closest_root; sc->d.shadow_root = h.shadow_root;
     sc->d.num_planes = (uint32_t)h.planes.size(); sc->d.num_lights = (uint32_t)h.lights.size();
     for (int a = 0; a < 3; ++a) sc->d.background[a] = h.background[a];

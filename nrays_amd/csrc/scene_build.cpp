@@ -262,6 +262,22 @@ int build_host_scene(const NraysSceneDesc* d, HostScene& out, std::string& err) 
         r.refr_coeff = n.refr_coeff; r.pad[0] = has_uv ? 1u : 0u; r.pad[1] = 0;
         out.node_recs.push_back(r);
         {
+            ShadeRec sr; std::memset(&sr, 0, sizeof sr);
+            sr.refl_mix = n.refl_mix; sr.refl_atenuation = n.refl_atenuation; sr.alpha = n.alpha; sr.refr_coeff = n.refr_coeff;
+            sr.flags = (has_uv ? 1u : 0u) | (m.kind << 8);
+            for (int a = 0; a < 3; ++a) { sr.ka[a] = m.ambiant[a]; sr.kd[a] = m.diffuse[a]; sr.ks[a] = m.specular[a]; }
+            sr.shininess = m.shininess;
+            auto fill = [&](ShadeTex& t, int32_t id) {
+                if (id < 0) return;
+                const NraysTexture& x = d->textures[id];
+                t.width = x.width; t.height = x.height; t.mode = x.format | (x.interp << 8) | (x.overflow << 16);
+            };
+            fill(sr.tex, m.texture_id); fill(sr.alpha_tex, m.alpha_texture_id);
+            out.shade.push_back(sr);
+            out.shade_tex.push_back(m.texture_id < 0 ? -1 : m.texture_id);
+            out.shade_alpha_tex.push_back(m.alpha_texture_id < 0 ? -1 : m.alpha_texture_id);
+        }
+        {
             float mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
             if (n.shape_kind == NRAYS_SHAPE_TRIMESH) { // local AABB = union of the faces' vertices (TriMesh BVT root)
                 const NraysMesh& m = d->meshes[n.mesh_id];

@@ -23,6 +23,8 @@ struct HostScene {
     std::vector<InstLink> links, shadow_links; // parallel to instances / shadow_instances
     std::vector<int32_t> planes, shadow_planes;
     std::vector<NodeRec> node_recs;
+    std::vector<ShadeRec> shade;             // per node; texel pointers patched after the texture upload
+    std::vector<int32_t> shade_tex, shade_alpha_tex; // texture indices behind shade[i].tex / alpha_tex (-1 = none)
     std::vector<double> node_aabbs;          // 6 per node (mins, maxs), reference arithmetic
     std::vector<MaterialRec> materials;
     std::vector<HostTexture> textures;

@@ -420,10 +420,10 @@ __device__ __noinline__ bool cast_analytic(const Instance& in, d3 o, d3 d, Isect
 }
 
 // ---------------------------------------------------------------- textures & materials -------
-NR_DEV f4 tex_at(const TextureRec& t, uint32_t x, uint32_t y) {
+NR_DEV f4 tex_at(const ShadeTex& t, uint32_t x, uint32_t y) {
     size_t i = (size_t)y * t.width + x;
     f4 r;
-    if (t.format == NRAYS_TEXEL_RGBA8) {
+    if ((t.mode & 0xffu) == NRAYS_TEXEL_RGBA8) {
         uchar4 p = ((const uchar4*)t.texels)[i];
         r.x = (float)p.x / 255.0f; r.y = (float)p.y / 255.0f; r.z = (float)p.z / 255.0f; r.w = (float)p.w / 255.0f;
     } else {
@@ -434,10 +434,10 @@ NR_DEV f4 tex_at(const TextureRec& t, uint32_t x, uint32_t y) {
 }
 // Texture2d::sample (texture2d.rs:207-256), taps clamped to the last row/column.
 template <bool STATS>
-NR_DEV f4 tex_sample(const TextureRec& t, double u, double v, Cnt& cnt) {
+NR_DEV f4 tex_sample(const ShadeTex& t, double u, double v, Cnt& cnt) {
     if (STATS) cnt.tex++;
     float ux = (float)u, uy = (float)v;
-    if (t.overflow == NRAYS_OVERFLOW_CLAMP) {
+    if (((t.mode >> 16) & 0xffu) == NRAYS_OVERFLOW_CLAMP) {
         ux = ux < 0.0f ? 0.0f : (ux > 1.0f ? 1.0f : ux);
         uy = uy < 0.0f ? 0.0f : (uy > 1.0f ? 1.0f : uy);
     } else {
@@ -448,7 +448,7 @@ NR_DEV f4 tex_sample(const TextureRec& t, double u, double v, Cnt& cnt) {
     ux = ux * (float)(t.width - 1);
     uy = uy * (float)(t.height - 1);
     uint32_t wm = t.width - 1, hm = t.height - 1;
-    if (t.interp == NRAYS_INTERP_NEAREST) {
+    if (((t.mode >> 8) & 0xffu) == NRAYS_INTERP_NEAREST) {
         uint32_t x = (uint32_t)roundf(ux), y = (uint32_t)roundf(uy);
         if (x > wm) x = wm;
         if (y > hm) y = hm;
@@ -471,21 +471,22 @@ NR_DEV f4 tex_sample(const TextureRec& t, double u, double v, Cnt& cnt) {
 
 // Material::ambiant (phong_material.rs:39-70, normal_material.rs:9-14, uv_material.rs:10-20).
 template <bool STATS>
-NR_DEV f4 material_ambiant(const DScene& S, const MaterialRec& m, const Isect& in, Cnt& cnt) {
+NR_DEV f4 material_ambiant(const ShadeRec& m, const Isect& in, Cnt& cnt) {
     f4 r;
-    if (m.kind == NRAYS_MAT_NORMAL) {
+    const uint32_t kind = (m.flags >> 8) & 0xffu;
+    if (kind == NRAYS_MAT_NORMAL) {
         r.x = (1.0f + (float)in.n.x) / 2.0f; r.y = (1.0f + (float)in.n.y) / 2.0f; r.z = (1.0f + (float)in.n.z) / 2.0f; r.w = 1.0f;
         return r;
     }
-    if (m.kind == NRAYS_MAT_UV) {
+    if (kind == NRAYS_MAT_UV) {
         if (in.has_uv) { r.x = (float)in.u; r.y = (float)in.v; r.z = 0.0f; r.w = 1.0f; }
         else { r.x = r.y = r.z = r.w = 0.0f; }
         return r;
     }
     if (in.has_uv) {
         f4 tc; tc.x = tc.y = tc.z = tc.w = 1.0f;
-        if (m.tex >= 0) { tc = tex_sample<STATS>(S.textures[m.tex], in.u, in.v, cnt); tc.w = 1.0f; }
-        if (m.alpha_tex >= 0) tc.w = tex_sample<STATS>(S.textures[m.alpha_tex], in.u, in.v, cnt).w;
+        if (m.tex.texels) { tc = tex_sample<STATS>(m.tex, in.u, in.v, cnt); tc.w = 1.0f; }
+        if (m.alpha_tex.texels) tc.w = tex_sample<STATS>(m.alpha_tex, in.u, in.v, cnt).w;
         r.x = m.ka[0] * tc.x; r.y = m.ka[1] * tc.y; r.z = m.ka[2] * tc.z; r.w = 1.0f * tc.w;
     } else { r.x = m.ka[0]; r.y = m.ka[1]; r.z = m.ka[2]; r.w = 1.0f; }
     return r;
@@ -621,7 +622,7 @@ NR_DEV bool resolve_hit(const DScene& S, d3 o, d3 d, const Hit& h, Isect& out, u
     out.toi = toi;
     out.n = (in.flags & kInstIdentityRot) ? n : rot(m, n);
     node_id = tr.node_id;
-    out.has_uv = (S.node_recs[node_id].pad[0] & 1u) != 0;
+    out.has_uv = (S.shade[node_id].flags & 1u) != 0;
     out.u = 0.0; out.v = 0.0;
     if (out.has_uv) {
         const TriUv& uv = S.triuvs[h.prim];
@@ -635,8 +636,8 @@ NR_DEV bool resolve_hit(const DScene& S, d3 o, d3 d, const Hit& h, Isect& out, u
 template <bool STATS>
 NR_DEV bool shadow_node_hit(const DScene& S, uint32_t node_id, const Isect& is, f3& filter, Cnt& cnt) {
     if (STATS) cnt.hit++;
-    const NodeRec& nr = S.node_recs[node_id];
-    f4 color = material_ambiant<STATS>(S, S.materials[nr.material_id], is, cnt);
+    const ShadeRec& nr = S.shade[node_id];
+    f4 color = material_ambiant<STATS>(nr, is, cnt);
     float alpha = color.w * nr.alpha;
     if (alpha < 1.0f) {
         filter.x = (filter.x * color.x) * (1.0f - alpha);
@@ -703,16 +704,27 @@ NR_DEV bool traverse(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, Hit&
             float k0 = (t0 >= 0.0f && ch.x != kEmptyChild) ? t0 : kMiss, k1 = (t1 >= 0.0f && ch.y != kEmptyChild) ? t1 : kMiss;
             float k2 = (t2 >= 0.0f && ch.z != kEmptyChild) ? t2 : kMiss, k3 = (t3 >= 0.0f && ch.w != kEmptyChild) ? t3 : kMiss;
             int32_t c0 = ch.x, c1 = ch.y, c2 = ch.z, c3 = ch.w;
-            // 5-comparator sorting network on (key, ref): ascending entry distance
+            if (!SHADOW) {
+                // closest hit: 5-comparator sorting network on (key, ref), ascending entry distance;
+                // farthest first onto the stack, nearest becomes the next node
 #define NR_CSWAP(ka, ca, kb, cb) { bool sw = kb < ka; float tk = sw ? kb : ka; kb = sw ? ka : kb; ka = tk; int32_t tc = sw ? cb : ca; cb = sw ? ca : cb; ca = tc; }
-            NR_CSWAP(k0, c0, k1, c1) NR_CSWAP(k2, c2, k3, c3) NR_CSWAP(k0, c0, k2, c2) NR_CSWAP(k1, c1, k3, c3) NR_CSWAP(k1, c1, k2, c2)
+                NR_CSWAP(k0, c0, k1, c1) NR_CSWAP(k2, c2, k3, c3) NR_CSWAP(k0, c0, k2, c2) NR_CSWAP(k1, c1, k3, c3) NR_CSWAP(k1, c1, k2, c2)
 #undef NR_CSWAP
-            // farthest first onto the stack, nearest becomes the next node
-            if (k3 < kMiss) st.push(c3);
-            if (k2 < kMiss) st.push(c2);
-            if (k1 < kMiss) st.push(c1);
-            if (k0 < kMiss) cur = c0;
-            else cur = st.sp ? st.pop() : kEmptyChild;
+                if (k3 < kMiss) st.push(c3);
+                if (k2 < kMiss) st.push(c2);
+                if (k1 < kMiss) st.push(c1);
+                if (k0 < kMiss) cur = c0;
+                else cur = st.sp ? st.pop() : kEmptyChild;
+            } else {
+                // shadow rays are any-hit (or per-node closest with a result that does not depend on the
+                // visiting order): no sort, every hit child but the last found goes onto the stack
+                cur = kEmptyChild;
+                if (k0 < kMiss) cur = c0;
+                if (k1 < kMiss) { if (cur != kEmptyChild) st.push(cur); cur = c1; }
+                if (k2 < kMiss) { if (cur != kEmptyChild) st.push(cur); cur = c2; }
+                if (k3 < kMiss) { if (cur != kEmptyChild) st.push(cur); cur = c3; }
+                if (cur == kEmptyChild) cur = st.sp ? st.pop() : kEmptyChild;
+            }
         }
         NR_TOC(cyc_node, tphase);
         if (cur == kEmptyChild) break;
@@ -826,12 +838,12 @@ NR_DEV bool shadow_query(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, 
 }
 #endif
 template <bool STATS, int FEAT>
-NR_MAT_ATTR f4 material_compute(const DScene& S, Stack& st, const MaterialRec& m, const RayState& ray, d3 point, const Isect& in, Cnt& cnt) {
-    if (m.kind != NRAYS_MAT_PHONG) return material_ambiant<STATS>(S, m, in, cnt);
+NR_MAT_ATTR f4 material_compute(const DScene& S, Stack& st, const ShadeRec& m, const RayState& ray, d3 point, const Isect& in, Cnt& cnt) {
+    if (((m.flags >> 8) & 0xffu) != NRAYS_MAT_PHONG) return material_ambiant<STATS>(m, in, cnt);
     f4 tex; tex.x = tex.y = tex.z = tex.w = 1.0f;
     float alpha = 1.0f;
-    if (in.has_uv && m.tex >= 0) tex = tex_sample<STATS>(S.textures[m.tex], in.u, in.v, cnt);
-    if (in.has_uv && m.alpha_tex >= 0) alpha = tex_sample<STATS>(S.textures[m.alpha_tex], in.u, in.v, cnt).w;
+    if (in.has_uv && m.tex.texels) tex = tex_sample<STATS>(m.tex, in.u, in.v, cnt);
+    if (in.has_uv && m.alpha_tex.texels) alpha = tex_sample<STATS>(m.alpha_tex, in.u, in.v, cnt).w;
     f3 res = F3(m.ka[0] * tex.x, m.ka[1] * tex.y, m.ka[2] * tex.z);
     d3 normal = in.n;
 #pragma nounroll
@@ -940,9 +952,9 @@ NR_DEV f3 shade_hit(const DScene& S, Stack& st, RayState& ray, uint32_t depth, u
     }
     is.toi = hit.t;
     if (STATS) cnt.hit++;
-    const NodeRec& sn = S.node_recs[node_id];
+    const ShadeRec& sn = S.shade[node_id];
     d3 pt = ray.o + ray.d * hit.t;
-    f4 obj = material_compute<STATS, FEAT>(S, st, S.materials[sn.material_id], ray, pt, is, cnt);
+    f4 obj = material_compute<STATS, FEAT>(S, st, sn, ray, pt, is, cnt);
     bool may_recurse = depth < (uint32_t)kMaxGenerations && (max_depth == 0 || depth < max_depth);
     float mix = sn.refl_mix;
     float alpha = obj.w * sn.alpha;
