@@ -96,7 +96,7 @@ __device__ __forceinline__ void flush_counters(DeviceCounters* ctr, const Cnt& c
 
 // Waves per SIMD requested per permutation (measured on MI355X, tools/kbench.py): the opaque mesh
 // kernel is latency-bound and prefers 3 waves with a few spills; the others run best at 2 without.
-constexpr int waves_per_simd(int feat) { return feat == kFeatMesh ? (NRAYS_WAVES_PER_SIMD > 3 ? NRAYS_WAVES_PER_SIMD : 3) : NRAYS_WAVES_PER_SIMD; }
+constexpr int waves_per_simd(int feat) { return (feat & ~kFeatMultiSample) == kFeatMesh ? (NRAYS_WAVES_PER_SIMD > 3 ? NRAYS_WAVES_PER_SIMD : 3) : NRAYS_WAVES_PER_SIMD; }
 
 template <bool STATS, int FEAT>
 __global__ void __launch_bounds__(kBlock, waves_per_simd(FEAT)) k_primary(DScene S, DRender R, QueueOut qo, float* __restrict__ out, DeviceCounters* ctr,
@@ -350,14 +350,21 @@ static void launch_primary(bool instrumented, int features, uint32_t grid, hipSt
                            uint32_t* zero_counts, DeviceCounters* zero_ctr) {
 #define NR_LAUNCH(F) hipLaunchKernelGGL((k_primary<false, F>), dim3(grid), dim3(kBlock), 0, stream, d, R, qo, out, ctr, spill, tx, ty, work, grab, zero_counts, zero_ctr)
     if (instrumented) { hipLaunchKernelGGL((k_primary<true, kFeatAll>), dim3(grid), dim3(kBlock), 0, stream, d, R, qo, out, ctr, spill, tx, ty, work, grab, zero_counts, zero_ctr); return; }
-    switch (features) { // bit 8 (double branching) only with its prerequisite bit 4 (non-opaque nodes)
+    switch (features) { // bit 8 (double branching) only in the full kernels; bit 16 = multi-sample lighting
     case 1: NR_LAUNCH(1); break;
     case 2: NR_LAUNCH(2); break;
     case 3: NR_LAUNCH(3); break;
     case 5: NR_LAUNCH(5); break;
     case 6: NR_LAUNCH(6); break;
     case 7: NR_LAUNCH(7); break;
-    default: NR_LAUNCH(15); break;
+    case 15: NR_LAUNCH(15); break;
+    case 17: NR_LAUNCH(17); break;
+    case 18: NR_LAUNCH(18); break;
+    case 19: NR_LAUNCH(19); break;
+    case 21: NR_LAUNCH(21); break;
+    case 22: NR_LAUNCH(22); break;
+    case 23: NR_LAUNCH(23); break;
+    default: NR_LAUNCH(31); break;
     }
 #undef NR_LAUNCH
 }

@@ -388,6 +388,7 @@ int build_host_scene(const NraysSceneDesc* d, HostScene& out, std::string& err) 
         }
         if (f == 4 || f == 0) f |= 1; // empty scenes take the lightest kernel
         if (out.any_double_branch) f = 15; // reflection + refraction at one hit: full kernel with the HBM queue
+        if (!(d->num_lights == 1 && d->lights[0].racsample == 1)) f |= 16; // more than one light sample per hit
         out.features = f;
     }
     out.closest_root = append_tlas(cinst, cbox, out);

@@ -39,7 +39,9 @@ enum Features : int {
     kFeatMesh = 2,         // TriMesh nodes exist (BLAS traversal, ray/triangle)
     kFeatAlphaShadow = 4,  // some node may be non-opaque to shadow rays (per-node closest hit + colour filter)
     kFeatDouble = 8,       // some node can spawn a reflection AND a refraction at one hit (second child -> HBM queue)
-    kFeatAll = 15
+    kFeatMultiSample = 16, // more than one light sample per hit: shadow rays are traced inside the light loop;
+                           // otherwise the single shadow ray is traced before the shading state exists
+    kFeatAll = 31
 };
 
 // ---------------------------------------------------------------- vector algebra (f64) -------
@@ -838,7 +840,8 @@ NR_DEV bool shadow_query(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, 
 }
 #endif
 template <bool STATS, int FEAT>
-NR_MAT_ATTR f4 material_compute(const DScene& S, Stack& st, const ShadeRec& m, const RayState& ray, d3 point, const Isect& in, Cnt& cnt) {
+NR_MAT_ATTR f4 material_compute(const DScene& S, Stack& st, const ShadeRec& m, const RayState& ray, d3 point, const Isect& in, Cnt& cnt,
+                                bool pre, bool pre_lit, f3 pre_filter) {
     if (((m.flags >> 8) & 0xffu) != NRAYS_MAT_PHONG) return material_ambiant<STATS>(m, in, cnt);
     f4 tex; tex.x = tex.y = tex.z = tex.w = 1.0f;
     float alpha = 1.0f;
@@ -866,8 +869,13 @@ NR_MAT_ATTR f4 material_compute(const DScene& S, Stack& st, const ShadeRec& m, c
             double dist = nrm - 0.001;
             d3 so = point + ldir * 0.001;
             f3 filter = F3(1.0f, 1.0f, 1.0f);
-            cnt.shadow++;
-            if (shadow_query<STATS, FEAT>(S, st, so, ldir, dist, filter, cnt)) continue; // shadowed
+            if (!(FEAT & kFeatMultiSample)) { // the single shadow ray of this hit was traced before the shading state existed
+                if (!pre || !pre_lit) continue;
+                filter = pre_filter;
+            } else {
+                cnt.shadow++;
+                if (shadow_query<STATS, FEAT>(S, st, so, ldir, dist, filter, cnt)) continue; // shadowed
+            }
             double dot_ldir_norm = dot(ldir, normal);
             float dcoeff = (float)dot_ldir_norm;
             dcoeff = dcoeff > 0.0f ? dcoeff : 0.0f;
@@ -944,17 +952,39 @@ NR_DEV f3 shade_hit(const DScene& S, Stack& st, RayState& ray, uint32_t depth, u
     Hit hit; f3 nofilter = F3(1.0f, 1.0f, 1.0f);
     Isect is; uint32_t node_id;
     bool gated = false;
+    bool pre = false, pre_lit = false; f3 pre_filter = F3(1.0f, 1.0f, 1.0f);
     for (;;) { // second iteration only when the ungated winner fails the reference's AABB gates (knife-edge rays)
         if (!traverse<false, STATS, FEAT>(S, st, ray.o, ray.d, kDblMax, hit, nofilter, cnt, gated))
             return F3(S.background[0] * ray.weight, S.background[1] * ray.weight, S.background[2] * ray.weight);
         if (resolve_hit<false, FEAT, true>(S, ray.o, ray.d, hit, is, node_id) || gated) break;
         gated = true;
     }
+    // Single-sample lighting (one point light, or one area light with racsample 1): trace the shadow ray NOW,
+    // while only the ray, the hit distance and the chain state are live, and hand the result to the Phong
+    // evaluation below — the normal / uv / texture state then never has to survive a traversal.  Same ray,
+    // same result as phong_material.rs:109-112; only the evaluation order differs.
+    if (!(FEAT & kFeatMultiSample) && S.num_lights == 1 && ((S.shade[node_id].flags >> 8) & 0xffu) == NRAYS_MAT_PHONG) {
+        const LightRec& light = S.lights[0];
+        if (light.racsample == 1u) {
+            d3 pos = D3(light.pos[0], light.pos[1], light.pos[2]);
+            if (light.radius != 0.0) {
+                unsigned long long sk = rng_hash(rng_hash(ray.key, kSaltLight), 0);
+                pos = pos + D3(rng_u01(sk, 0), rng_u01(sk, 1), rng_u01(sk, 2)) * light.radius;
+            }
+            d3 point = ray.o + ray.d * hit.t;
+            d3 ldir = pos - point;
+            double nrm = norm(ldir);
+            ldir = ldir / nrm;
+            cnt.shadow++;
+            pre = true;
+            pre_lit = !shadow_query<STATS, FEAT>(S, st, point + ldir * 0.001, ldir, nrm - 0.001, pre_filter, cnt);
+        }
+    }
     is.toi = hit.t;
     if (STATS) cnt.hit++;
     const ShadeRec& sn = S.shade[node_id];
     d3 pt = ray.o + ray.d * hit.t;
-    f4 obj = material_compute<STATS, FEAT>(S, st, sn, ray, pt, is, cnt);
+    f4 obj = material_compute<STATS, FEAT>(S, st, sn, ray, pt, is, cnt, pre, pre_lit, pre_filter);
     bool may_recurse = depth < (uint32_t)kMaxGenerations && (max_depth == 0 || depth < max_depth);
     float mix = sn.refl_mix;
     float alpha = obj.w * sn.alpha;
