@@ -182,6 +182,11 @@ struct DRender {
     double eye[3];
     double m[16];                // (P V)^-1 column-major
     unsigned long long seed;
+    // Without AA jitter the primary ray of pixel (i, j) only needs M[:,0] * dx_i and M[:,1] * dy_j: tabulated
+    // once per camera by k_raygen_tables (4 f64 per column / row, same operations as the in-kernel path, so
+    // bit-identical); null when window_width != 0.
+    const double* col_tab;
+    const double* row_tab;
 };
 
 } // namespace nrays

@@ -32,7 +32,6 @@ namespace nrays {
 constexpr int kTile = 16;          // a workgroup renders a 16x16 pixel tile
 constexpr int kNumCounts = kMaxGenerations + 2 + 8; // queue round counters + 8 per-XCD work counters
 constexpr int kMaxGrid = 2048;     // persistent grid: 256 CUs x 8 workgroups
-constexpr int kSpillDepth = 96;    // HBM spill entries per lane (only allocated for very deep trees)
 
 // XCD-aware dynamic scheduling of the persistent grid.  The tiles (in row-major order) are cut into 8
 // contiguous ranges, one per XCD, each with its own work counter in HBM.  A workgroup reads the id
@@ -226,6 +225,21 @@ __global__ void __launch_bounds__(kBlock, NRAYS_WAVES_PER_SIMD) k_bounce(DScene 
     flush_counters(ctr, cnt, STATS);
 }
 
+// Per-column / per-row raygen products for jitter-free cameras (see DRender::col_tab): thread t < width
+// writes M[:,0] * dx_t, thread width + t writes M[:,1] * dy_t, with exactly the operations of
+// generate_primary (scene.rs:81-83), so the tabulated path is bit-identical to the direct one.
+__global__ void k_raygen_tables(double* col_tab, double* row_tab, uint32_t width, uint32_t height, DRender R) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < width) {
+        double dx = ((double)t / (double)width - 0.5) * 2.0;
+        for (int r = 0; r < 4; ++r) col_tab[4 * (size_t)t + r] = R.m[r] * dx;
+    } else if (t < width + height) {
+        uint32_t j = t - width;
+        double dy = -((double)j / (double)height - 0.5) * 2.0;
+        for (int r = 0; r < 4; ++r) row_tab[4 * (size_t)j + r] = R.m[4 + r] * dy;
+    }
+}
+
 __global__ void k_resolve(float* out, size_t n, float spp) { // pxs.push(tot_c / ray_per_pixel as f32), scene.rs:94
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = out[i] / spp;
@@ -281,7 +295,10 @@ struct NraysScene {
     DeviceCounters* d_counters = nullptr; // set used by the last frame
     uint64_t launch_index = 0, frame_index = 0;
     uint32_t* d_spill = nullptr;
-    bool need_spill = false;
+    double* d_tables = nullptr; size_t tables_doubles = 0; // raygen tables: 4 * (width + height) f64
+    uint32_t tab_w = 0, tab_h = 0; double tab_m[16] = {0}; bool tab_valid = false;
+    uint32_t spill_entries = 0; // HBM stack entries per lane beyond the kLdsStack entries kept in LDS (0 = never needed)
+    int num_cus = 256;
     int features = kFeatAll;
     float* d_frame = nullptr; size_t frame_floats = 0;
     hipStream_t own_stream = nullptr;
@@ -393,8 +410,8 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
         int rc = ensure_queue(sc, (uint32_t)want);
         if (rc != NRAYS_OK) return rc;
     }
-    if (sc->need_spill && !sc->d_spill) {
-        HIP_TRY(hipMalloc((void**)&sc->d_spill, (size_t)kMaxGrid * kBlock * kSpillDepth * sizeof(uint32_t)));
+    if (sc->spill_entries && !sc->d_spill) {
+        HIP_TRY(hipMalloc((void**)&sc->d_spill, (size_t)kMaxGrid * kBlock * sc->spill_entries * sizeof(uint32_t)));
     }
 
     DRender R; std::memset(&R, 0, sizeof R);
@@ -410,7 +427,9 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
     const uint32_t ntiles = tiles_x * tiles_y;
     uint32_t grab = (sc->features & kFeatMesh) ? 1u : 0u; // 0 = static wave-interleaved assignment
     if (const char* e = getenv("NRAYS_GRAB")) grab = (uint32_t)std::max(0, atoi(e)); // scheduling A/B override (tools/kbench.py); pixels do not depend on it
-    const uint32_t grid_primary = std::min<uint32_t>(((ntiles + 7u) / 8u) * 8u, 256u * (uint32_t)waves_per_simd(instrumented ? kFeatAll : sc->features));
+    // persistent grid: exactly the workgroups that can be resident (one 4-wave workgroup per CU per wave/SIMD)
+    const uint32_t grid_primary = std::min<uint32_t>(std::min<uint32_t>(((ntiles + 7u) / 8u) * 8u, (uint32_t)kMaxGrid),
+                                                     (uint32_t)sc->num_cus * (uint32_t)waves_per_simd(instrumented ? kFeatAll : sc->features));
 
     const int slot = (int)(sc->frames_recorded % NraysScene::kRing);
     // events: [pbegin .. pend] brackets the first primary launch; the frame spans [pbegin .. end], and
@@ -420,6 +439,22 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
     DeviceCounters* next_ctr = sc->d_counters_set[(sc->frame_index + 1) & 1];
     sc->frame_index++;
     R.use_rng = (p->window_width != 0.0 || sc->host.any_area_light) ? 1u : 0u;
+    R.col_tab = nullptr; R.row_tab = nullptr;
+    if (p->window_width == 0.0) { // jitter-free camera: (re)build the raygen tables only when the camera or the resolution changed
+        size_t need = 4 * ((size_t)p->width + p->height);
+        if (need > sc->tables_doubles) {
+            if (sc->d_tables) { (void)hipFree(sc->d_tables); sc->d_tables = nullptr; sc->tables_doubles = 0; }
+            HIP_TRY(hipMalloc((void**)&sc->d_tables, need * sizeof(double)));
+            sc->tables_doubles = need; sc->tab_valid = false;
+        }
+        R.col_tab = sc->d_tables; R.row_tab = sc->d_tables + 4 * (size_t)p->width;
+        if (!sc->tab_valid || sc->tab_w != p->width || sc->tab_h != p->height || std::memcmp(sc->tab_m, p->inv_proj_view, sizeof sc->tab_m) != 0) {
+            uint32_t n = p->width + p->height;
+            hipLaunchKernelGGL(k_raygen_tables, dim3((n + 255) / 256), dim3(256), 0, stream, sc->d_tables, sc->d_tables + 4 * (size_t)p->width, p->width, p->height, R);
+            HIP_TRY(hipGetLastError());
+            sc->tab_w = p->width; sc->tab_h = p->height; std::memcpy(sc->tab_m, p->inv_proj_view, sizeof sc->tab_m); sc->tab_valid = true;
+        }
+    }
     bool first_primary = true;
     for (uint32_t s0 = 0; s0 < p->ray_per_pixel; s0 += batch) {
         R.sample_begin = s0; R.sample_end = std::min<uint32_t>(p->ray_per_pixel, s0 + batch);
@@ -524,7 +559,16 @@ int nrays_scene_create(const NraysSceneDesc* desc, NraysScene** out_scene) {
     sc->d.num_planes = (uint32_t)h.planes.size(); sc->d.num_lights = (uint32_t)h.lights.size();
     for (int a = 0; a < 3; ++a) sc->d.background[a] = h.background[a];
     // stack bound: one deferred sibling per level of TLAS and BLAS, plus the sentinel
-    sc->need_spill = (6 * h.max_bvh_depth + 4) > kLdsStack; // up to 3 deferred siblings per level, TLAS + BLAS
+    // worst-case stack use: up to 3 deferred siblings per level of TLAS + BLAS (max_bvh_depth bounds each),
+    // one sentinel, the plane pseudo-leaves, a little slack; whatever exceeds the LDS part spills to HBM
+    {
+        uint32_t need = 6u * (uint32_t)(h.max_bvh_depth + 1) + (uint32_t)h.planes.size() + 8u;
+        sc->spill_entries = need > (uint32_t)kLdsStack ? need - (uint32_t)kLdsStack : 0u;
+    }
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, sc->device) == hipSuccess && cus > 0) sc->num_cus = cus;
+    }
     sc->features = h.features ? h.features : kFeatAll;
     // release bulk host copies
     std::vector<BvhNode>().swap(h.nodes); std::vector<TriRec>().swap(h.tris); std::vector<TriUv>().swap(h.triuvs);
@@ -561,6 +605,7 @@ void nrays_scene_destroy(NraysScene* sc) {
     }
     if (sc->d_spill) (void)hipFree(sc->d_spill);
     if (sc->d_frame) (void)hipFree(sc->d_frame);
+    if (sc->d_tables) (void)hipFree(sc->d_tables);
     if (sc->d_counters_primary) (void)hipFree(sc->d_counters_primary);
     for (int k = 0; k < NraysScene::kRing; ++k) {
         if (sc->ev_begin[k]) (void)hipEventDestroy(sc->ev_begin[k]);

@@ -123,6 +123,7 @@ struct Isect {
     d3 n;
     double u, v;
     bool has_uv;
+    bool hit; // only meaningful on the value returned by cast_analytic
 };
 
 struct Xform { // Isometry3: R (row-major) and translation
@@ -407,18 +408,24 @@ NR_DEV void load_xform(const Instance& in, Xform& m) {
 }
 
 // SceneNode::cast for the analytic shapes (scene_node.rs:51-54).
-__device__ __noinline__ bool cast_analytic(const Instance& in, d3 o, d3 d, Isect& out) {
+// One out-of-line copy shared by the closest-hit and shadow paths.  The record is RETURNED (56 bytes: the
+// AMDGPU calling convention hands aggregates of up to 16 dwords back in VGPRs); an `Isect&` out-parameter
+// would live in scratch memory and cost a store + load round trip per call.
+__device__ __noinline__ Isect cast_analytic(const Instance& in, d3 o, d3 d) {
     bool solid = (in.flags & kInstSolid) != 0;
     Xform m; load_xform(in, m);
+    Isect out;
+    out.toi = 0.0; out.n = D3(0.0, 0.0, 0.0); out.u = 0.0; out.v = 0.0; out.has_uv = false; out.hit = false;
     switch (in.kind) {
-    case NRAYS_SHAPE_BALL: return cast_ball(in.params[0], m.t, o, d, solid, out);
-    case NRAYS_SHAPE_CUBOID: return cast_cuboid(D3(in.params[0], in.params[1], in.params[2]), m, o, d, solid, out);
-    case NRAYS_SHAPE_CYLINDER: return cast_cylinder(in.params[0], in.params[1], m, o, d, solid, out);
-    case NRAYS_SHAPE_CAPSULE: return cast_capsule(in.params[0], in.params[1], m, o, d, solid, out);
-    case NRAYS_SHAPE_CONE: return cast_cone(in.params[0], in.params[1], m, o, d, solid, out);
-    case NRAYS_SHAPE_PLANE: return cast_plane(D3(in.params[0], in.params[1], in.params[2]), m, o, d, solid, out);
-    default: return false;
+    case NRAYS_SHAPE_BALL: out.hit = cast_ball(in.params[0], m.t, o, d, solid, out); break;
+    case NRAYS_SHAPE_CUBOID: out.hit = cast_cuboid(D3(in.params[0], in.params[1], in.params[2]), m, o, d, solid, out); break;
+    case NRAYS_SHAPE_CYLINDER: out.hit = cast_cylinder(in.params[0], in.params[1], m, o, d, solid, out); break;
+    case NRAYS_SHAPE_CAPSULE: out.hit = cast_capsule(in.params[0], in.params[1], m, o, d, solid, out); break;
+    case NRAYS_SHAPE_CONE: out.hit = cast_cone(in.params[0], in.params[1], m, o, d, solid, out); break;
+    case NRAYS_SHAPE_PLANE: out.hit = cast_plane(D3(in.params[0], in.params[1], in.params[2]), m, o, d, solid, out); break;
+    default: break;
     }
+    return out;
 }
 
 // ---------------------------------------------------------------- textures & materials -------
@@ -608,7 +615,7 @@ template <bool SHADOW, int FEAT, bool CHECK = false>
 NR_DEV bool resolve_hit(const DScene& S, d3 o, d3 d, const Hit& h, Isect& out, uint32_t& node_id) {
     const Instance& in = (SHADOW ? S.shadow_instances : S.instances)[h.inst];
     if ((FEAT & kFeatAnalytic) && (!(FEAT & kFeatMesh) || in.kind != NRAYS_SHAPE_TRIMESH)) {
-        cast_analytic(in, o, d, out);
+        out = cast_analytic(in, o, d);
         node_id = (uint32_t)in.node_id;
         return !CHECK || in.kind == NRAYS_SHAPE_PLANE || node_aabb_pass(S, node_id, o, d);
     }
@@ -662,7 +669,13 @@ NR_DEV bool shadow_node_hit(const DScene& S, uint32_t node_id, const Isect& is, 
 // ungated minimum passes the gates it is also the gated minimum; if it fails (knife-edge rays only) the
 // caller re-runs the same traversal with gated_closest = true.
 template <bool SHADOW, bool STATS, int FEAT>
-NR_DEV bool traverse(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, Hit& hit, f3& filter, Cnt& cnt, bool gated_closest = false) {
+NR_DEV bool traverse(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, Hit& hit, f3& filter, Cnt& cnt, bool gated_closest = false,
+                     Isect* winner = nullptr) {
+    // Analytic-only scenes keep the winner's full record (no second cast in resolve_hit); scenes with meshes
+    // only carry (t, instance, triangle) through the loop and reconstruct the record afterwards.
+    constexpr bool kKeepIsect = !SHADOW && !(FEAT & kFeatMesh);
+    Isect bis;
+    if (kKeepIsect) { bis.toi = 0.0; bis.n = D3(0.0, 0.0, 0.0); bis.u = 0.0; bis.v = 0.0; bis.has_uv = false; bis.hit = false; }
     const bool GATED = SHADOW || gated_closest;
     constexpr bool kAnalytic = (FEAT & kFeatAnalytic) != 0, kMesh = (FEAT & kFeatMesh) != 0;
     constexpr bool kAlpha = (FEAT & kFeatAlphaShadow) != 0; // shadow mode: otherwise every hit within tlimit blocks
@@ -789,8 +802,8 @@ NR_DEV bool traverse(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, Hit&
         if (kAnalytic) { // TLAS leaf: an analytic shape (or a plane pseudo-leaf)
             const Instance& in = insts[first];
             if (STATS) cnt.prim++;
-            Isect is;
-            if (cast_analytic(in, o, d, is) && (!GATED || in.kind == NRAYS_SHAPE_PLANE || node_aabb_pass(S, (uint32_t)in.node_id, o, d))) {
+            Isect is = cast_analytic(in, o, d);
+            if (is.hit && (!GATED || in.kind == NRAYS_SHAPE_PLANE || node_aabb_pass(S, (uint32_t)in.node_id, o, d))) {
                 if (SHADOW) {
                     if (is.toi <= tlimit) {
                         if (!kAlpha) return true;
@@ -798,7 +811,10 @@ NR_DEV bool traverse(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, Hit&
                     }
                 } else {
                     unsigned long long key = (unsigned long long)(uint32_t)in.node_id << 32;
-                    if (is.toi < bt || (is.toi == bt && key < bkey)) { bt = is.toi; bkey = key; bhit = true; binst = first; bprim = 0; btf = best_f32(bt); }
+                    if (is.toi < bt || (is.toi == bt && key < bkey)) {
+                        bt = is.toi; bkey = key; bhit = true; binst = first; bprim = 0; btf = best_f32(bt);
+                        if (kKeepIsect) bis = is;
+                    }
                 }
             }
         }
@@ -807,6 +823,7 @@ NR_DEV bool traverse(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, Hit&
 
     if (SHADOW) return false;
     hit.t = bt; hit.inst = binst; hit.prim = bprim;
+    if (kKeepIsect && winner) *winner = bis;
     return bhit;
 }
 
@@ -954,9 +971,13 @@ NR_DEV f3 shade_hit(const DScene& S, Stack& st, RayState& ray, uint32_t depth, u
     bool gated = false;
     bool pre = false, pre_lit = false; f3 pre_filter = F3(1.0f, 1.0f, 1.0f);
     for (;;) { // second iteration only when the ungated winner fails the reference's AABB gates (knife-edge rays)
-        if (!traverse<false, STATS, FEAT>(S, st, ray.o, ray.d, kDblMax, hit, nofilter, cnt, gated))
+        if (!traverse<false, STATS, FEAT>(S, st, ray.o, ray.d, kDblMax, hit, nofilter, cnt, gated, &is))
             return F3(S.background[0] * ray.weight, S.background[1] * ray.weight, S.background[2] * ray.weight);
-        if (resolve_hit<false, FEAT, true>(S, ray.o, ray.d, hit, is, node_id) || gated) break;
+        if (!(FEAT & kFeatMesh)) { // `is` is the winner's record already; only the deferred AABB gate is left
+            const Instance& in = S.instances[hit.inst];
+            node_id = (uint32_t)in.node_id;
+            if (gated || in.kind == NRAYS_SHAPE_PLANE || node_aabb_pass(S, node_id, ray.o, ray.d)) break;
+        } else if (resolve_hit<false, FEAT, true>(S, ray.o, ray.d, hit, is, node_id) || gated) break;
         gated = true;
     }
     // Single-sample lighting (one point light, or one area light with racsample 1): trace the shadow ray NOW,
@@ -1047,16 +1068,23 @@ NR_DEV void generate_primary(const DRender& R, uint32_t i, uint32_t j, uint32_t 
         unsigned long long pkey = rng_hash(R.seed, (unsigned long long)i + (unsigned long long)j * R.width);
         skey = rng_hash(pkey, s);
     }
-    double ox = (double)i, oy = (double)j;
-    if (R.window_width != 0.0) {
-        ox = ox + (rng_u01(skey, 0) - 0.5) * R.window_width;
-        oy = oy + (rng_u01(skey, 1) - 0.5) * R.window_width;
-    }
-    double dx = (ox / (double)R.width - 0.5) * 2.0;
-    double dy = -(oy / (double)R.height - 0.5) * 2.0;
     double h[4];
+    if (R.col_tab) { // no jitter: h = ((M0*dx_i + M1*dy_j) + M2*(-1)) + M3*1 with the two products tabulated
+        const double* ct = R.col_tab + 4 * (size_t)i;
+        const double* rt = R.row_tab + 4 * (size_t)j;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) h[r] = R.m[r] * dx + R.m[4 + r] * dy + R.m[8 + r] * -1.0 + R.m[12 + r] * 1.0;
+        for (int r = 0; r < 4; ++r) h[r] = ct[r] + rt[r] + R.m[8 + r] * -1.0 + R.m[12 + r] * 1.0;
+    } else {
+        double ox = (double)i, oy = (double)j;
+        if (R.window_width != 0.0) {
+            ox = ox + (rng_u01(skey, 0) - 0.5) * R.window_width;
+            oy = oy + (rng_u01(skey, 1) - 0.5) * R.window_width;
+        }
+        double dx = (ox / (double)R.width - 0.5) * 2.0;
+        double dy = -(oy / (double)R.height - 0.5) * 2.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[r] = R.m[r] * dx + R.m[4 + r] * dy + R.m[8 + r] * -1.0 + R.m[12 + r] * 1.0;
+    }
     d3 eye = D3(h[0] / h[3], h[1] / h[3], h[2] / h[3]);
     d3 e0 = D3(R.eye[0], R.eye[1], R.eye[2]);
     ray.o = e0; ray.d = normalize(eye - e0); ray.refr = 1.0; ray.energy = 1.0f; ray.weight = 1.0f;

@@ -26,3 +26,7 @@ print("balls no reflection  ms %.4f kernel %.4f rays %d" % run(sc0, cam))
 sc1, _ = su.balls_scene(refl=(0.2, 0.25))
 print("balls 4 bounces      ms %.4f kernel %.4f rays %d" % run(sc1, cam))
 print("balls 4b max_depth 1 ms %.4f kernel %.4f rays %d" % run(sc1, cam, max_depth=1))
+for (w, h) in [(64, 64), (480, 270), (960, 540), (1920, 1080), (3840, 2160)]:
+    print("empty %4dx%4d      ms %.4f kernel %.4f rays %d" % ((w, h) + run(empty, cam, w, h)))
+for (w, h) in [(64, 64), (480, 270), (960, 540), (1920, 1080), (3840, 2160)]:
+    print("balls %4dx%4d      ms %.4f kernel %.4f rays %d" % ((w, h) + run(sc1, cam, w, h)))

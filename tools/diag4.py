@@ -1,16 +1,26 @@
-import ctypes as C, sys, os
+"""Floor analysis of the analytic-scene kernel: empty scene / balls at several resolutions (A/B via NRAYS_HIP_LIB)."""
+import ctypes as C, sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import torch
 import nrays_amd as nr
 from nrays_amd import abi
-from tests import scenes_util as su, standins
+from tests import scenes_util as su
 lib = abi.load_hip_lib()
-for name, (sc, cam) in {"sponza": standins.sponza_scene(), "hairball": standins.hairball_scene(), "balls": su.balls_scene()}.items():
-    p, _ = su.camera_params(cam, 1920, 1080)
-    out = torch.empty((1080, 1920, 3), dtype=torch.float32, device="cuda")
-    for _ in range(3):
-        abi.check(lib.nrays_render_device(sc.device_handle(), C.byref(p), C.c_void_p(out.data_ptr()), None))
+def run(sc, cam, w=1920, h=1080, steps=50, **kw):
+    p, _ = su.camera_params(cam, w, h, **kw)
+    out = torch.empty((h, w, 3), dtype=torch.float32, device="cuda")
+    hd = sc.device_handle()
+    for _ in range(5): abi.check(lib.nrays_render_device(hd, C.byref(p), C.c_void_p(out.data_ptr()), None))
+    nr.get_stats(sc)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(steps): abi.check(lib.nrays_render_device(hd, C.byref(p), C.c_void_p(out.data_ptr()), None))
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
     st = nr.get_stats(sc)
-    tot = st.prim_tests
-    print(name, "kernel ms %.3f" % st.kernel_ms_primary, "wave-cycles total %.3e  node-loop %.1f%%  leaf+sentinel phase %.1f%%  outside traversal %.1f%%" % (
-        tot, 100.0 * st.node_tests / tot, 100.0 * st.tri_tests / tot, 100.0 * (tot - st.node_tests - st.tri_tests) / tot))
+    return dt * 1e3, st.kernel_ms_primary, st.total_rays()
+cam = dict(eye=(0.0, 5.0, -10.0), at=(0.0, 0.0, 0.0), fovy=45.0)
+empty = nr.Scene([], [nr.Light((0, 10, 0), 0, 1, (1, 1, 1))])
+sc1, _ = su.balls_scene(refl=(0.2, 0.25))
+tag = os.environ.get("NRAYS_HIP_LIB", "default")
+for (w, h) in [(64, 64), (1920, 1080)]:
+    print(tag, "empty %4dx%4d      ms %.4f kernel %.4f rays %d" % ((w, h) + run(empty, cam, w, h)))
+    print(tag, "balls %4dx%4d      ms %.4f kernel %.4f rays %d" % ((w, h) + run(sc1, cam, w, h)))
