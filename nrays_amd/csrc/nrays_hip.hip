@@ -102,6 +102,11 @@ __global__ void __launch_bounds__(kBlock, waves_per_simd(FEAT)) k_primary(DScene
                                                      uint32_t* spill, uint32_t tiles_x, uint32_t tiles_y, uint32_t* work_counters, uint32_t grab,
                                                      uint32_t* zero_counts, DeviceCounters* zero_ctr) {
     __shared__ uint32_t lds_stack[kLdsStack * kBlock];
+    __shared__ uint32_t block_next; // grab == 0: next entry of this workgroup's tile list
+    if (grab == 0u) { // workgroup-uniform
+        if (threadIdx.x == 0) block_next = 0u;
+        __syncthreads();
+    }
     // Counters are double-buffered: this launch clears the set the NEXT launch / frame will use (nothing
     // else touches it while this kernel runs), which removes every hipMemsetAsync from the frame.
     if (blockIdx.x == 0) {
@@ -122,20 +127,27 @@ __global__ void __launch_bounds__(kBlock, waves_per_simd(FEAT)) k_primary(DScene
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t nwt = tiles_x * tiles_y * 4u; // wave tiles: 4 per 16x16 block
 
-    // grab == 0: static assignment, wave tiles interleaved over all resident waves (no atomics): expensive
-    // regions are spread evenly, which is what cheap analytic scenes want.  grab >= 1: dynamic.
-    const uint32_t total_waves = gridDim.x * (kBlock / 64), my_wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    // grab == 0 (cheap analytic scenes, ~1 us tiles): the wave tiles are dealt round-robin to the workgroups and
+    // the four waves of a workgroup pull from their list through an LDS counter — list scheduling inside the
+    // workgroup (a wave that drew a deep reflection chain does not hold back its siblings' share) without a
+    // single HBM atomic; device-scope atomics on one address retire at ~9 M/s on this part, far too slow
+    // for 32k tiles per 100 us frame.  grab >= 1: XCD-aware dynamic dequeue from HBM counters (mesh scenes).
+    // wave-uniform by construction: read through an SGPR so that the tile arithmetic stays on the scalar unit
+    const uint32_t total_waves = gridDim.x * (kBlock / 64);
+    const uint32_t my_wave = blockIdx.x * (kBlock / 64) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     uint32_t victim = xcc_id();
     const uint32_t g = grab ? grab : 1u;
     const uint32_t per = (((nwt + 7u) / 8u) + g - 1u) / g * g; // wave tiles per XCD range
     const bool prefetch = grab > 1u;
     uint32_t pending = grab ? issue_grab(work_counters, victim, grab) : 0u;
-    uint32_t static_next = my_wave;
     for (;;) {
       uint32_t first, last;
       if (grab == 0u) {
-          if (static_next >= nwt) break;
-          first = static_next; last = first + 1u; static_next += total_waves;
+          uint32_t k = 0;
+          if (lane == 0u) k = atomicAdd(&block_next, 1u); // LDS: ~100 cycles, no prefetch needed
+          first = (uint32_t)__builtin_amdgcn_readfirstlane((int)k) * gridDim.x + blockIdx.x;
+          if (first >= nwt) break;
+          last = first + 1u;
       } else {
           uint32_t k = (uint32_t)__builtin_amdgcn_readfirstlane((int)pending);
           uint32_t begin = victim * per, end = begin + per < nwt ? begin + per : nwt;
@@ -172,7 +184,15 @@ __global__ void __launch_bounds__(kBlock, waves_per_simd(FEAT)) k_primary(DScene
             RayState ray;
             generate_primary(R, i, j, s, pix, ray);
             unsigned node_before = cnt.node;
-            f3 c = trace_chain<STATS, FEAT>(S, st, active, ray, 0u, R.max_depth, qo, cnt);
+            f3 c;
+            if (__ballot(active && primary_may_hit(S, ray.o, ray.d)) == 0ULL) {
+                // no ray of this wave tile gets past the root of the BVT: Scene::trace returns the background for
+                // all of them (scene.rs:157-161), without entering the trace loop
+                c = F3(S.background[0], S.background[1], S.background[2]);
+                if (STATS && active && S.closest_root >= 0) cnt.node += 4;
+            } else {
+                c = trace_chain<STATS, FEAT>(S, st, active, ray, 0u, R.max_depth, qo, cnt);
+            }
             if (STATS) { unsigned dn = cnt.node - node_before; if (dn > cnt.max_chain_nodes) cnt.max_chain_nodes = dn; }
             tot.x = tot.x + c.x; tot.y = tot.y + c.y; tot.z = tot.z + c.z;
         }
@@ -429,7 +449,7 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
     if (const char* e = getenv("NRAYS_GRAB")) grab = (uint32_t)std::max(0, atoi(e)); // scheduling A/B override (tools/kbench.py); pixels do not depend on it
     // persistent grid: exactly the workgroups that can be resident (one 4-wave workgroup per CU per wave/SIMD)
     const uint32_t grid_primary = std::min<uint32_t>(std::min<uint32_t>(((ntiles + 7u) / 8u) * 8u, (uint32_t)kMaxGrid),
-                                                     (uint32_t)sc->num_cus * (uint32_t)waves_per_simd(instrumented ? kFeatAll : sc->features));
+                                                     (uint32_t)sc->num_cus * (uint32_t)waves_per_simd(instrumented ? kFeatAll : sc->features) * 256u / (uint32_t)kBlock);
 
     const int slot = (int)(sc->frames_recorded % NraysScene::kRing);
     // events: [pbegin .. pend] brackets the first primary launch; the frame spans [pbegin .. end], and

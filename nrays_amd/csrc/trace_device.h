@@ -26,7 +26,7 @@
 
 namespace nrays {
 
-constexpr int kBlock = 256;     // threads per workgroup = 4 wave64
+constexpr int kBlock = 256;     // threads per workgroup = 4 wave64 (8-wave workgroups measured slower: 100 vs 86 us on balls)
 constexpr int kLdsStack = 32;   // traversal-stack entries kept in LDS per lane (then spills to HBM)
 constexpr int32_t kSentinel = (int32_t)0x80000001; // marks "leave the BLAS" on the traversal stack
 
@@ -575,6 +575,25 @@ NR_DEV void box_entry4(float4 mnx, float4 mny, float4 mnz, float4 mxx, float4 mx
     t1 = (n1 * 0.9999995f <= f1 * 1.0000005f) ? n1 : -1.0f;
     t2 = (n2 * 0.9999995f <= f2_ * 1.0000005f) ? n2 : -1.0f;
     t3 = (n3 * 0.9999995f <= f3 * 1.0000005f) ? n3 : -1.0f;
+}
+
+// Whether a primary ray can reach anything at all: exactly the first step of traverse<false> (same f32
+// ray view, same root fetch, same conservative box test), so "false" means that traversal would return
+// a miss and Scene::trace the background colour.  k_primary uses it to let wave tiles of empty screen
+// skip the trace machinery altogether.
+NR_DEV bool primary_may_hit(const DScene& S, d3 o, d3 d) {
+    if (S.num_planes) return true; // planes are unbounded
+    int32_t cur = S.closest_root;
+    if (cur == kEmptyChild) return false;
+    if (cur < 0) return true; // single leaf: no box above it
+    RayF rf = make_rayf(o, d);
+    const float4* q = (const float4*)(S.nodes + cur);
+    float4 mnx = q[0], mny = q[1], mnz = q[2], mxx = q[3], mxy = q[4], mxz = q[5];
+    int4 ch = ((const int4*)q)[6];
+    float t0, t1, t2, t3;
+    box_entry4(mnx, mny, mnz, mxx, mxy, mxz, rf, best_f32(kDblMax), t0, t1, t2, t3);
+    return (t0 >= 0.0f && ch.x != kEmptyChild) || (t1 >= 0.0f && ch.y != kEmptyChild) ||
+           (t2 >= 0.0f && ch.z != kEmptyChild) || (t3 >= 0.0f && ch.w != kEmptyChild);
 }
 
 // ncollide ray_aabb (AABB::toi_with_ray, solid = true; SURVEY B-3) as a predicate, in f64 and in the
