@@ -26,6 +26,9 @@ def run_one(scene_name, steps, width, height, check):
     lib = abi.load_hip_lib()
     if scene_name == "balls":
         sc, cam = su.balls_scene()
+    elif scene_name == "ballsaway":  # every wave tile misses the scene: the cheap path alone
+        sc, cam = su.balls_scene()
+        cam = dict(cam, at=(0.0, 5.0, -30.0))
     elif scene_name == "sponza":
         sc, cam = standins.sponza_scene()
     elif scene_name == "sponza8":
