@@ -690,7 +690,8 @@ int nrays_get_primary_kernel_stats(NraysScene* sc, NraysStats* out) {
     HIP_TRY(hipMemcpy(&c, sc->d_counters_primary, sizeof c, hipMemcpyDeviceToHost));
     out->rays_primary = sc->last_primary_first_batch;
     fill_counters(out, c);
-    out->rays_reflection = 0; out->rays_refraction = 0; // continuation rays are traced by the bounce kernels
+    // single continuations (reflection OR refraction) are traced by the primary kernel itself (trace_chain); only the
+    // second child of a double branch goes through the queue to k_bounce, after this snapshot was taken
     out->instrumented = 1;
     return NRAYS_OK;
 }
