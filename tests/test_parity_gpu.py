@@ -222,3 +222,43 @@ def test_area_lights_on_meshes_and_eight_lights(gpu):
     sc._descriptor = None
     _, _, st, _ = compare(sc, cam, 80, 60, seed=5)
     assert st.rays_shadow > 4 * 2 * 80 * 60 * 0.3
+
+
+def test_one_scene_handle_many_cameras_and_resolutions(gpu):
+    """The raygen tables are cached per (camera, resolution) on the scene handle: changing either between
+    renders of the same handle must rebuild them (and jittered frames must bypass them)."""
+    sc, cam = su.balls_scene(tex_size=(64, 32))
+    cams = [cam, dict(cam, eye=(3.0, 2.0, -7.0)), dict(cam, at=(0.5, 0.2, 0.0), fovy=60.0), cam]
+    for c, (w, h) in zip(cams, [(160, 90), (160, 90), (96, 120), (200, 64)]):
+        compare(sc, c, w, h)
+    compare(sc, cam, 64, 48, spp=2, window=1.0, seed=5)
+    compare(sc, cam, 64, 48)
+
+
+def test_empty_screen_tiles_and_single_leaf_roots(gpu):
+    """Wave tiles whose rays all miss the root of the BVT are finished without entering the trace loop: a camera
+    that looks away (every tile), a scene whose root is a single leaf (no box above it), a scene with a plane
+    (never skipped), banded tiles with padding rows."""
+    sc, cam = su.balls_scene(tex_size=(64, 32))
+    away = dict(cam, at=(0.0, 5.0, -30.0))
+    img, _, st, _ = compare(sc, away, 150, 70)
+    assert st.rays_shadow == 0 and np.all(img == 1.0)
+    one = nr.Scene([nr.SceneNode(su.default_material(), 0.3, 0.5, 1.0, 1.0, nr.Isometry3((0.5, 0.0, 0.0)), nr.Ball(1.0))],
+                   [nr.Light((0.0, 10.0, 0.0), 0.0, 1, (1, 1, 1))], (0.1, 0.2, 0.3))
+    compare(one, cam, 120, 80)
+    prim, pcam = su.primitives_scene(light_radius=0.0, nsample=1)
+    compare(prim, dict(pcam, at=(0.0, 8.0, 0.0)), 96, 64)  # half of the frame sees only the sky... and the plane's horizon
+    import torch
+    from nrays_amd import tiling
+    lib = abi.load_hip_lib()
+    full, _ = su.camera_params(cam, 100, 52)
+    ref, _ = oracle.render(sc.descriptor, full, 4)
+    for rank in range(3):
+        p = tiling.tile_params(full, rank, 3, 16)
+        rows = lib.nrays_tile_rows(C.byref(p))
+        out = torch.full((rows, 100, 3), -7.0, dtype=torch.float32, device="cuda")
+        abi.check(lib.nrays_render_device(sc.device_handle(), C.byref(p), C.c_void_p(out.data_ptr()), None))
+        got = out.cpu().numpy()
+        own = tiling.owned_rows(52, 16, rank, 3)
+        assert np.abs(got[:len(own)] - ref[own]).max() <= TOL
+        assert np.all(got[len(own):] == 0.0)  # padding rows of the last band are zero-filled, also by skipped tiles
