@@ -187,6 +187,10 @@ struct DRender {
     // bit-identical); null when window_width != 0.
     const double* col_tab;
     const double* row_tab;
+    // Mesh scenes (dynamic dequeue): per-wave-tile cost of this frame (written) and the wave tiles in
+    // descending order of the previous frame's cost (read; null = image order).  Scheduling only.
+    uint32_t* tile_cost;
+    const uint32_t* tile_order;
 };
 
 } // namespace nrays

@@ -149,24 +149,30 @@ __global__ void __launch_bounds__(kBlock, waves_per_simd(FEAT)) k_primary(DScene
           if (first >= nwt) break;
           last = first + 1u;
       } else {
+          // XCD x owns a list of wave tiles: without history the contiguous range [x * per, (x + 1) * per) of the
+          // image; with the previous frame's costs the entries x, x + 8, x + 16, ... of the descending-cost order
+          // (longest-processing-time-first: the deep alpha / reflection chains start first, the frame ends on
+          // cheap tiles).
+          const bool ordered = R.tile_order != nullptr;
           uint32_t k = (uint32_t)__builtin_amdgcn_readfirstlane((int)pending);
-          uint32_t begin = victim * per, end = begin + per < nwt ? begin + per : nwt;
-          first = begin + k;
-          if (begin >= end || first >= end) { // this XCD's range is exhausted: steal from the next non-empty one
+          uint32_t len = ordered ? (nwt > victim ? (nwt - victim + 7u) / 8u : 0u) : (victim * per < nwt ? (nwt - victim * per < per ? nwt - victim * per : per) : 0u);
+          if (k >= len) { // this XCD's list is exhausted: steal from the next non-empty one
               bool found = false;
               for (uint32_t tries = 0; tries < 7u && !found; ++tries) {
                   victim = (victim + 1u) & 7u;
-                  begin = victim * per; end = begin + per < nwt ? begin + per : nwt;
-                  if (begin >= end) continue;
+                  len = ordered ? (nwt > victim ? (nwt - victim + 7u) / 8u : 0u) : (victim * per < nwt ? (nwt - victim * per < per ? nwt - victim * per : per) : 0u);
+                  if (len == 0u) continue;
                   k = (uint32_t)__builtin_amdgcn_readfirstlane((int)issue_grab(work_counters, victim, grab));
-                  if (begin + k < end) { first = begin + k; found = true; }
+                  if (k < len) found = true;
               }
               if (!found) break; // wave-uniform
           }
-          last = first + grab < end ? first + grab : end;
+          if (ordered) { first = R.tile_order[k * 8u + victim]; last = first + 1u; }
+          else { first = victim * per + k; last = k + grab < len ? first + grab : victim * per + len; }
           if (prefetch) pending = issue_grab(work_counters, victim, grab); // issued now, consumed after the tiles below
       }
       for (uint32_t wt = first; wt < last; ++wt) {
+        const unsigned long long tile_t0 = R.tile_cost ? __builtin_readcyclecounter() : 0ULL;
         uint32_t tile = wt >> 2, sub = wt & 3u;
         uint32_t tx = tile % tiles_x, ty = tile / tiles_x;
         uint32_t lx = ((sub & 1u) << 3) | (lane & 7u), ly = ((sub >> 1) << 3) | (lane >> 3);
@@ -203,6 +209,10 @@ __global__ void __launch_bounds__(kBlock, waves_per_simd(FEAT)) k_primary(DScene
         } else if (i < R.width && rl < R.rows_local && R.first_batch) { // padding rows of the last band
             float* o = out + (size_t)pix * 3;
             o[0] = 0.0f; o[1] = 0.0f; o[2] = 0.0f;
+        }
+        if (R.tile_cost && lane == 0u) { // wave cycles spent on this tile, for the next frame's order
+            unsigned long long dt = (__builtin_readcyclecounter() - tile_t0) >> 4;
+            R.tile_cost[wt] = dt > 0xffffffffULL ? 0xffffffffu : (uint32_t)dt;
         }
       }
       if (grab == 1u) pending = issue_grab(work_counters, victim, grab);
@@ -243,6 +253,31 @@ __global__ void __launch_bounds__(kBlock, NRAYS_WAVES_PER_SIMD) k_bounce(DScene 
         }
     }
     flush_counters(ctr, cnt, STATS);
+}
+
+// Wave tiles in descending order of last frame's cost.  XCD x's work list is the subset { i : i mod 8 == x } of the
+// wave tiles (a uniform sample of the image), sorted by workgroup x with a 256-bucket counting sort in LDS
+// on (exponent, 3 mantissa bits) of the cycle counts — an approximate order is all a work queue needs.
+// Entry k of list x is stored at order[8 k + x].
+__device__ __forceinline__ uint32_t cost_bucket(uint32_t c) {
+    if (c == 0u) return 0u;
+    uint32_t e = 31u - (uint32_t)__clz((int)c);
+    uint32_t m = e >= 3u ? (c >> (e - 3u)) & 7u : (c << (3u - e)) & 7u;
+    return e * 8u + m;
+}
+__global__ void __launch_bounds__(1024) k_tile_order(const uint32_t* __restrict__ cost, uint32_t* __restrict__ order, uint32_t n) {
+    __shared__ uint32_t hist[256];
+    const uint32_t x = blockIdx.x; // 0..7
+    if (threadIdx.x < 256u) hist[threadIdx.x] = 0u;
+    __syncthreads();
+    for (uint32_t i = x + 8u * threadIdx.x; i < n; i += 8u * 1024u) atomicAdd(&hist[cost_bucket(cost[i])], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) { // exclusive prefix, most expensive bucket first
+        uint32_t acc = 0u;
+        for (int b = 255; b >= 0; --b) { uint32_t c = hist[b]; hist[b] = acc; acc += c; }
+    }
+    __syncthreads();
+    for (uint32_t i = x + 8u * threadIdx.x; i < n; i += 8u * 1024u) order[8u * atomicAdd(&hist[cost_bucket(cost[i])], 1u) + x] = i;
 }
 
 // Per-column / per-row raygen products for jitter-free cameras (see DRender::col_tab): thread t < width
@@ -317,6 +352,10 @@ struct NraysScene {
     uint32_t* d_spill = nullptr;
     double* d_tables = nullptr; size_t tables_doubles = 0; // raygen tables: 4 * (width + height) f64
     uint32_t tab_w = 0, tab_h = 0; double tab_m[16] = {0}; bool tab_valid = false;
+    // previous frame's wave-tile costs (k_primary) and the order derived from them (k_tile_order); valid for one
+    // (width, rows, band) geometry at a time
+    uint32_t* d_tile_cost = nullptr; uint32_t* d_tile_order = nullptr; uint32_t tile_slots = 0;
+    uint64_t cost_key = 0; bool cost_valid = false;
     uint32_t spill_entries = 0; // HBM stack entries per lane beyond the kLdsStack entries kept in LDS (0 = never needed)
     int num_cus = 256;
     int features = kFeatAll;
@@ -327,6 +366,7 @@ struct NraysScene {
     static constexpr int kRing = 256;
     hipEvent_t ev_begin[kRing] = {}, ev_pbegin[kRing] = {}, ev_pend[kRing] = {}, ev_end[kRing] = {};
     bool single_launch[kRing] = {};
+    bool has_prepass[kRing] = {}; // the frame started with k_tile_order: ev_begin was recorded before it
     uint64_t frames_recorded = 0, frames_reported = 0;
     DeviceCounters* d_counters_primary = nullptr; // snapshot taken right after the primary kernel
     hipStream_t last_stream = nullptr;
@@ -474,6 +514,33 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
             HIP_TRY(hipGetLastError());
             sc->tab_w = p->width; sc->tab_h = p->height; std::memcpy(sc->tab_m, p->inv_proj_view, sizeof sc->tab_m); sc->tab_valid = true;
         }
+    }
+    // mesh scenes: longest-processing-time-first from the previous frame of the same geometry (pixels do not depend on it)
+    R.tile_cost = nullptr; R.tile_order = nullptr;
+    sc->has_prepass[slot] = false;
+    bool lpt = grab >= 1u;
+    if (const char* e = getenv("NRAYS_LPT")) lpt = lpt && atoi(e) != 0; // A/B switch (tools/kbench.py)
+    if (lpt) {
+        const uint32_t nwt = ntiles * 4u;
+        if (nwt > sc->tile_slots) {
+            if (sc->d_tile_cost) { (void)hipFree(sc->d_tile_cost); sc->d_tile_cost = nullptr; }
+            if (sc->d_tile_order) { (void)hipFree(sc->d_tile_order); sc->d_tile_order = nullptr; }
+            sc->tile_slots = 0; sc->cost_valid = false;
+            HIP_TRY(hipMalloc((void**)&sc->d_tile_cost, (size_t)nwt * sizeof(uint32_t)));
+            HIP_TRY(hipMalloc((void**)&sc->d_tile_order, (size_t)nwt * sizeof(uint32_t)));
+            sc->tile_slots = nwt;
+        }
+        const uint64_t key = ((uint64_t)p->width << 40) ^ ((uint64_t)rows << 20) ^ ((uint64_t)p->band_rows << 8) ^ ((uint64_t)p->band_owner << 4) ^ (uint64_t)R.band_owners;
+        if (sc->cost_valid && sc->cost_key == key) {
+            HIP_TRY(hipEventRecord(sc->ev_begin[slot], stream));
+            sc->has_prepass[slot] = true;
+            hipLaunchKernelGGL(k_tile_order, dim3(8), dim3(1024), 0, stream, sc->d_tile_cost, sc->d_tile_order, nwt);
+            HIP_TRY(hipGetLastError());
+            R.tile_order = sc->d_tile_order;
+            grab = 1u;
+        }
+        R.tile_cost = sc->d_tile_cost;
+        sc->cost_key = key; sc->cost_valid = true;
     }
     bool first_primary = true;
     for (uint32_t s0 = 0; s0 < p->ray_per_pixel; s0 += batch) {
@@ -626,6 +693,8 @@ void nrays_scene_destroy(NraysScene* sc) {
     if (sc->d_spill) (void)hipFree(sc->d_spill);
     if (sc->d_frame) (void)hipFree(sc->d_frame);
     if (sc->d_tables) (void)hipFree(sc->d_tables);
+    if (sc->d_tile_cost) (void)hipFree(sc->d_tile_cost);
+    if (sc->d_tile_order) (void)hipFree(sc->d_tile_order);
     if (sc->d_counters_primary) (void)hipFree(sc->d_counters_primary);
     for (int k = 0; k < NraysScene::kRing; ++k) {
         if (sc->ev_begin[k]) (void)hipEventDestroy(sc->ev_begin[k]);
@@ -671,7 +740,7 @@ int nrays_get_stats(NraysScene* sc, NraysStats* out) {
         int k = (int)(f % NraysScene::kRing);
         float ms_p = 0.f, ms_t = 0.f;
         if (hipEventElapsedTime(&ms_p, sc->ev_pbegin[k], sc->ev_pend[k]) == hipSuccess &&
-            hipEventElapsedTime(&ms_t, sc->ev_pbegin[k], sc->single_launch[k] ? sc->ev_pend[k] : sc->ev_end[k]) == hipSuccess) { sum_p += ms_p; sum_t += ms_t; ++n; }
+            hipEventElapsedTime(&ms_t, sc->has_prepass[k] ? sc->ev_begin[k] : sc->ev_pbegin[k], sc->single_launch[k] ? sc->ev_pend[k] : sc->ev_end[k]) == hipSuccess) { sum_p += ms_p; sum_t += ms_t; ++n; }
     }
     sc->frames_reported = sc->frames_recorded;
     if (n) { out->kernel_ms_primary = sum_p / (double)n; out->kernel_ms_total = sum_t / (double)n; }
