@@ -262,3 +262,30 @@ def test_empty_screen_tiles_and_single_leaf_roots(gpu):
         own = tiling.owned_rows(52, 16, rank, 3)
         assert np.abs(got[:len(own)] - ref[own]).max() <= TOL
         assert np.all(got[len(own):] == 0.0)  # padding rows of the last band are zero-filled, also by skipped tiles
+
+
+def test_mesh_frames_scheduled_from_last_frames_tile_costs(gpu):
+    """Mesh scenes order their wave tiles by the previous frame's per-tile cost (k_tile_order): frames 2.. of one
+    handle and geometry run through the sorted work lists and must stay identical to frame 1 and to the oracle,
+    also after a geometry change and with band tiling."""
+    import torch
+    from nrays_amd import tiling
+    lib = abi.load_hip_lib()
+    sc, cam = su.mesh_scene()
+    p, _ = su.camera_params(cam, 200, 120)
+    ref, _ = oracle.render(sc.descriptor, p, 8)
+    frames = [hip_render(sc, p)[0] for _ in range(4)]
+    assert np.abs(frames[0] - ref).max() <= TOL
+    for f in frames[1:]:
+        assert np.array_equal(f, frames[0])
+    p2, _ = su.camera_params(cam, 97, 61)  # geometry change: the history of the 200x120 frames must not be used
+    ref2, _ = oracle.render(sc.descriptor, p2, 8)
+    for _ in range(3):
+        assert np.abs(hip_render(sc, p2)[0] - ref2).max() <= TOL
+    for _ in range(2):
+        assert np.array_equal(hip_render(sc, p)[0], frames[0])
+    bp = tiling.tile_params(p, 1, 2, 16)
+    own = tiling.owned_rows(120, 16, 1, 2)
+    for _ in range(3):
+        got = hip_render(sc, bp)[0]
+        assert np.array_equal(got[:len(own)], frames[0][own])
