@@ -22,7 +22,11 @@ void rotation_from_axis_angle(const double w[3], double R[9], bool& identity) {
         return;
     }
     identity = false;
-    double s = std::sin(angle / 2.0), qw = std::cos(angle / 2.0);
+    // two separate libm calls, like Rust's f64::sin_cos: a merged sincos() differs in the last bit for ~0.16 % of
+    // the angles (glibc), which is enough to flip knife-edge hits several bounces later
+    static double (*volatile libm_sin)(double) = std::sin;
+    static double (*volatile libm_cos)(double) = std::cos;
+    double s = libm_sin(angle / 2.0), qw = libm_cos(angle / 2.0);
     double qi = w[0] / angle * s, qj = w[1] / angle * s, qk = w[2] / angle * s;
     double ww = qw * qw, ii = qi * qi, jj = qj * qj, kk = qk * qk;
     double ij = qi * qj * 2.0, wk = qw * qk * 2.0, wj = qw * qj * 2.0, ik = qi * qk * 2.0, jk = qj * qk * 2.0, wi = qw * qi * 2.0;

@@ -281,6 +281,8 @@ static int bvt_best_first(const Bvt* t, CostFn* fn, int* out_leaf, Inter* out_in
 /* ------------------------------------------------------------------------------------------ */
 typedef struct { double m[3][3]; v3 t; } Iso; /* m = rotation matrix R (local -> world) */
 
+static double (*volatile libm_sin)(double) = sin;
+static double (*volatile libm_cos)(double) = cos;
 static void iso_from_axis_angle(Iso* iso, const double t[3], const double w[3]) {
     double angle = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
     iso->t = V(t[0], t[1], t[2]);
@@ -289,7 +291,9 @@ static void iso_from_axis_angle(Iso* iso, const double t[3], const double w[3]) 
         return;
     }
     /* unit quaternion (w, i, j, k) = (cos(a/2), axis*sin(a/2)), then its rotation matrix */
-    double s = sin(angle / 2.0), qw = cos(angle / 2.0);
+    /* nalgebra: (angle / 2).sin_cos() = two separate libm calls; a compiler that merges them into sincos() gets
+     * a different last bit for ~0.16 % of the angles (glibc), hence the volatile function pointers */
+    double s = libm_sin(angle / 2.0), qw = libm_cos(angle / 2.0);
     double qi = w[0] / angle * s, qj = w[1] / angle * s, qk = w[2] / angle * s;
     double ww = qw * qw, ii = qi * qi, jj = qj * qj, kk = qk * qk;
     double ij = qi * qj * 2.0, wk = qw * qk * 2.0, wj = qw * qj * 2.0, ik = qi * qk * 2.0, jk = qj * qk * 2.0, wi = qw * qi * 2.0;

@@ -289,3 +289,17 @@ def test_mesh_frames_scheduled_from_last_frames_tile_costs(gpu):
     for _ in range(3):
         got = hip_render(sc, bp)[0]
         assert np.array_equal(got[:len(own)], frames[0][own])
+
+
+def test_randomised_scenes_sweep(gpu):
+    """tools/fuzz_parity.py on a fixed seed range: random shape mixes, rotations, reflection / refraction / alpha
+    coefficients, light sets, AA windows, depth caps; every case twice (the second frame of a mesh scene runs
+    through the cost-ordered work lists).  Pixels within 1e-4, ray-class counts exactly equal."""
+    import subprocess
+    import sys
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "5000", "60"], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert "0 mismatches" in r.stdout
