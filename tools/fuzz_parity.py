@@ -20,9 +20,18 @@ lib = abi.load_hip_lib()
 def random_scene(seed):
     rng = np.random.default_rng(seed)
     sc, cam = su.random_shapes_scene(seed, n=int(rng.integers(4, 40)), with_mesh=bool(rng.random() < 0.7))
-    d = sc  # rebuild with random coefficients
+    d = sc  # rebuild with random coefficients and materials
+    tex = [su.checker_texture(32, 4), su.checker_texture(16, 3), None]
+    amap = [su.checker_texture(32, 6, alpha_holes=True), None, None]
+    def material():
+        k = int(rng.integers(0, 6))
+        if k == 0: return nr.NormalMaterial()
+        if k == 1: return nr.UVMaterial()
+        return nr.PhongMaterial(tuple(rng.uniform(0, 0.3, 3)), tuple(rng.uniform(0.2, 1, 3)), tuple(rng.uniform(0, 1, 3)),
+                                tex[int(rng.integers(0, 3))], amap[int(rng.integers(0, 3))], float(rng.choice([5.0, 30.0, 100.0])))
     nodes = []
     for nd in d._nodes:
+        nd.material = material() if rng.random() < 0.8 else nd.material
         refl_mix = float(rng.choice([0.0, 0.0, 0.2, 0.5]))
         refl_att = float(rng.choice([0.2, 0.3, 0.5]))
         alpha = float(rng.choice([1.0, 1.0, 1.0, 0.4])) if (refl_mix == 0.0 or rng.random() < 0.15) else 1.0  # double branching is rare
@@ -37,13 +46,59 @@ def random_scene(seed):
     return nr.Scene(nodes, lights, tuple(rng.uniform(0, 1, 3))), cam, rng
 
 
+def random_mesh_scene(seed):
+    """Triangle soups: several TriMesh nodes, some sharing one isometry (merged into one BLAS), some rotated, some
+    alpha-mapped / transparent / reflective, exact duplicates of triangles across nodes (ties broken by node and
+    triangle index), degenerate slivers, plus a few analytic shapes."""
+    rng = np.random.default_rng(seed)
+    isos = [nr.Isometry3((0.0, 0.0, 0.0)), nr.Isometry3(tuple(rng.uniform(-1, 1, 3)), tuple(rng.uniform(-1.5, 1.5, 3))),
+            nr.Isometry3(tuple(rng.uniform(-2, 2, 3)))]
+    tex = [su.checker_texture(32, 4), su.checker_texture(16, 3), None]
+    amap = [su.checker_texture(32, 6, alpha_holes=True), None, None]
+    nodes, prev = [], None
+    for k in range(int(rng.integers(2, 7))):
+        nt = int(rng.integers(4, 200))
+        ctr = rng.uniform(-4, 4, (nt, 1, 3)) * np.array([1.0, 0.6, 1.0])
+        tri = su.f32_exact((ctr + rng.normal(0, float(rng.choice([0.2, 0.8, 2.0])), (nt, 3, 3))).reshape(-1, 3))
+        if rng.random() < 0.2:
+            tri[3:6] = tri[0:3]                      # an exact duplicate inside the node
+            tri[8] = tri[7]                          # a degenerate triangle
+        iso = isos[int(rng.integers(0, 3))]
+        if prev is not None and rng.random() < 0.4:  # copy a few triangles of the previous node: exact ties across nodes
+            m = min(len(prev[0]), len(tri), 30) // 3 * 3
+            tri[:m] = prev[0][:m]
+            iso = prev[1]
+        idx = np.arange(3 * nt, dtype=np.uint32).reshape(nt, 3)
+        uvs = su.f32_exact(rng.uniform(-1, 2, (3 * nt, 2))) if rng.random() < 0.8 else None
+        mat = nr.PhongMaterial(tuple(rng.uniform(0, 0.3, 3)), tuple(rng.uniform(0.2, 1, 3)), tuple(rng.uniform(0, 1, 3)),
+                               tex[int(rng.integers(0, 3))] if uvs is not None else None,
+                               amap[int(rng.integers(0, 3))] if uvs is not None else None, float(rng.choice([5.0, 30.0, 100.0])))
+        refl = float(rng.choice([0.0, 0.0, 0.3]))
+        alpha = float(rng.choice([1.0, 1.0, 0.5])) if refl == 0.0 else 1.0
+        nodes.append(nr.SceneNode(mat, refl, 0.3, alpha, float(rng.choice([1.0, 1.2])), iso, nr.TriMesh(tri, idx, uvs)))
+        prev = (tri, iso)
+    for _ in range(int(rng.integers(0, 3))):
+        nodes.append(nr.SceneNode(su.default_material(), float(rng.choice([0.0, 0.3])), 0.4, 1.0, 1.0,
+                                  nr.Isometry3(tuple(rng.uniform(-4, 4, 3)), tuple(rng.uniform(-1, 1, 3))),
+                                  [nr.Ball(0.8), nr.Cuboid((0.6, 0.4, 0.9)), nr.Cone(0.7, 0.5)][int(rng.integers(0, 3))]))
+    if rng.random() < 0.5:
+        nodes.append(nr.SceneNode(su.default_material(), 0.2, 0.5, 1.0, 1.0, nr.Isometry3((0, -5.0, 0)), nr.Plane((0, 1, 0))))
+    lights = []
+    for _ in range(int(rng.choice([1, 1, 2, 3]))):
+        rad = float(rng.choice([0.0, 0.0, 0.4]))
+        lights.append(nr.Light(tuple(rng.uniform(-8, 8, 3) + np.array([0, 10, 0])), rad, int(rng.choice([1, 3])) if rad > 0 else 1,
+                               tuple(rng.uniform(0.3, 1.0, 3))))
+    cam = dict(eye=tuple(rng.uniform(-3, 3, 3) + np.array([0.0, 2.0, -14.0])), at=(0.0, 0.0, 0.0), fovy=float(rng.choice([35.0, 50.0, 70.0])))
+    return nr.Scene(nodes, lights, tuple(rng.uniform(0, 1, 3))), cam, rng
+
+
 def main():
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 24
     worst, bad = 0.0, 0
     for seed in range(first, first + count):
         try:
-            sc, cam, rng = random_scene(seed)
+            sc, cam, rng = random_mesh_scene(seed) if seed % 2 else random_scene(seed)
         except AttributeError as e:
             print("scene construction needs attribute:", e); return 2
         w, h = int(rng.integers(40, 200)), int(rng.integers(30, 140))
