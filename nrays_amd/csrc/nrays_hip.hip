@@ -197,7 +197,7 @@ __global__ void __launch_bounds__(kBlock, waves_per_simd(FEAT)) k_primary(DScene
                 c = F3(S.background[0], S.background[1], S.background[2]);
                 if (STATS && active && S.closest_root >= 0) cnt.node += 4;
             } else {
-                c = trace_chain<STATS, FEAT>(S, st, active, ray, 0u, R.max_depth, qo, cnt);
+                c = trace_chain<STATS, FEAT>(S, st, active, ray, 0u, R.max_depth, qo, cnt, R.use_rng != 0u);
             }
             if (STATS) { unsigned dn = cnt.node - node_before; if (dn > cnt.max_chain_nodes) cnt.max_chain_nodes = dn; }
             tot.x = tot.x + c.x; tot.y = tot.y + c.y; tot.z = tot.z + c.z;
@@ -246,7 +246,7 @@ __global__ void __launch_bounds__(kBlock, NRAYS_WAVES_PER_SIMD) k_bounce(DScene 
         ray.o = D3(0, 0, 0); ray.d = D3(0, 0, 1); ray.refr = 1.0; ray.energy = 0.0f; ray.weight = 0.0f; ray.key = 0; ray.pixel = 0;
         uint32_t depth = 0;
         if (active) queue_load(qin, idx, ray, depth);
-        f3 c = trace_chain<STATS, kFeatAll>(S, st, active, ray, depth, max_depth, qo, cnt);
+        f3 c = trace_chain<STATS, kFeatAll>(S, st, active, ray, depth, max_depth, qo, cnt, true);
         if (active) {
             float* o = out + (size_t)ray.pixel * 3;
             unsafeAtomicAdd(o, c.x); unsafeAtomicAdd(o + 1, c.y); unsafeAtomicAdd(o + 2, c.z);

@@ -983,7 +983,7 @@ NR_DEV void emit_rays(const QueueOut& qo, bool has, const RayState& r, uint32_t 
 // continuation (has_next); a second continuation (only possible in kFeatDouble scenes) goes to `extra`.
 template <bool STATS, int FEAT>
 NR_DEV f3 shade_hit(const DScene& S, Stack& st, RayState& ray, uint32_t depth, uint32_t max_depth,
-                    bool& has_next, bool& has_extra, RayState& extra, Cnt& cnt) {
+                    bool& has_next, bool& has_extra, RayState& extra, Cnt& cnt, bool keyed) {
     has_next = false; has_extra = false;
     Hit hit; f3 nofilter = F3(1.0f, 1.0f, 1.0f);
     Isect is; uint32_t node_id;
@@ -1042,7 +1042,7 @@ NR_DEV f3 shade_hit(const DScene& S, Stack& st, RayState& ray, uint32_t depth, u
         d3 new_dir = normalize(dirn + tangent * (n2 / n1));
         RayState rt;
         rt.o = pt + new_dir * 0.001; rt.d = new_dir; rt.refr = n2; rt.energy = ray.energy;
-        rt.weight = ray.weight * (1.0f - alpha); rt.key = rng_hash(ray.key, kSaltRefr); rt.pixel = ray.pixel;
+        rt.weight = ray.weight * (1.0f - alpha); rt.key = keyed ? rng_hash(ray.key, kSaltRefr) : 0ULL; rt.pixel = ray.pixel;
         cnt.refr++;
         if (do_refl) { if (FEAT & kFeatDouble) { extra = rt; has_extra = true; } }
         else { ray = rt; has_next = true; return contrib; }
@@ -1050,7 +1050,7 @@ NR_DEV f3 shade_hit(const DScene& S, Stack& st, RayState& ray, uint32_t depth, u
     if (do_refl) { // scene.rs:204-214
         d3 rdir = ray.d - dirn * 2.0;
         ray.o = pt + rdir * 0.001; ray.d = rdir; ray.energy = ray.energy - sn.refl_atenuation;
-        ray.weight = wa * mix; ray.key = rng_hash(ray.key, kSaltRefl);
+        ray.weight = wa * mix; ray.key = keyed ? rng_hash(ray.key, kSaltRefl) : 0ULL;
         has_next = true; cnt.refl++;
     }
     return contrib;
@@ -1061,16 +1061,17 @@ NR_DEV f3 shade_hit(const DScene& S, Stack& st, RayState& ray, uint32_t depth, u
 // when a hit spawns both, the refraction ray goes to the compacted HBM queue and is picked up by a
 // k_bounce launch.  Returns the sum of the chain's weighted contributions to ray.pixel.
 // Must be called by every lane of the wave (inactive lanes pass alive = false).
+// `keyed`: the frame consumes RNG keys (AA jitter or an area light); otherwise the per-bounce key hashes are skipped.
 template <bool STATS, int FEAT>
 NR_DEV f3 trace_chain(const DScene& S, Stack& st, bool alive, RayState ray, uint32_t depth, uint32_t max_depth,
-                      const QueueOut& qo, Cnt& cnt) {
+                      const QueueOut& qo, Cnt& cnt, bool keyed) {
     f3 sum = F3(0.0f, 0.0f, 0.0f);
     while (__ballot(alive) != 0ULL) { // wave-uniform
         bool has_extra = false;
         RayState extra;
         if (FEAT & kFeatDouble) extra = ray;
         if (alive) {
-            f3 c = shade_hit<STATS, FEAT>(S, st, ray, depth, max_depth, alive, has_extra, extra, cnt);
+            f3 c = shade_hit<STATS, FEAT>(S, st, ray, depth, max_depth, alive, has_extra, extra, cnt, keyed);
             sum.x = sum.x + c.x; sum.y = sum.y + c.y; sum.z = sum.z + c.z;
             if (depth > cnt.max_depth) cnt.max_depth = depth;
         }
@@ -1084,7 +1085,9 @@ NR_DEV f3 trace_chain(const DScene& S, Stack& st, bool alive, RayState ray, uint
 NR_DEV void generate_primary(const DRender& R, uint32_t i, uint32_t j, uint32_t s, uint32_t pixel_out, RayState& ray) {
     unsigned long long skey = 0;
     if (R.use_rng) { // keys are only ever consumed by AA jitter and area-light sampling
-        unsigned long long pkey = rng_hash(R.seed, (unsigned long long)i + (unsigned long long)j * R.width);
+        unsigned long long pix = (unsigned long long)i + (unsigned long long)j * R.width;
+        asm volatile("" : "+v"(pix)); // keeps the (sample-invariant) pixel hash from being hoisted out of this branch
+        unsigned long long pkey = rng_hash(R.seed, pix);
         skey = rng_hash(pkey, s);
     }
     double h[4];
