@@ -97,7 +97,7 @@ __device__ __forceinline__ void flush_counters(DeviceCounters* ctr, const Cnt& c
 // kernel is latency-bound and prefers 3 waves with a few spills; the others run best at 2 without.
 constexpr int waves_per_simd(int feat) { return (feat & ~kFeatMultiSample) == kFeatMesh ? (NRAYS_WAVES_PER_SIMD > 3 ? NRAYS_WAVES_PER_SIMD : 3) : NRAYS_WAVES_PER_SIMD; }
 
-template <bool STATS, int FEAT>
+template <bool STATS, int FEAT, bool PLAIN = false>
 __global__ void __launch_bounds__(kBlock, waves_per_simd(FEAT)) k_primary(DScene S, DRender R, QueueOut qo, float* __restrict__ out, DeviceCounters* ctr,
                                                      uint32_t* spill, uint32_t tiles_x, uint32_t tiles_y, uint32_t* work_counters, uint32_t grab,
                                                      uint32_t* zero_counts, DeviceCounters* zero_ctr) {
@@ -186,9 +186,10 @@ __global__ void __launch_bounds__(kBlock, waves_per_simd(FEAT)) k_primary(DScene
         bool active = i < R.width && rl < R.rows_local && j < R.height;
         uint32_t pix = rl * R.width + i;
         f3 tot = F3(0.0f, 0.0f, 0.0f);
-        for (uint32_t s = R.sample_begin; s < R.sample_end; ++s) {
+        const uint32_t s_begin = PLAIN ? 0u : R.sample_begin, s_end = PLAIN ? 1u : R.sample_end;
+        for (uint32_t s = s_begin; s < s_end; ++s) {
             RayState ray;
-            generate_primary(R, i, j, s, pix, ray);
+            generate_primary<PLAIN>(R, i, j, s, pix, ray);
             unsigned node_before = cnt.node;
             f3 c;
             if (__ballot(active && primary_may_hit(S, ray.o, ray.d)) == 0ULL) {
@@ -197,16 +198,16 @@ __global__ void __launch_bounds__(kBlock, waves_per_simd(FEAT)) k_primary(DScene
                 c = F3(S.background[0], S.background[1], S.background[2]);
                 if (STATS && active && S.closest_root >= 0) cnt.node += 4;
             } else {
-                c = trace_chain<STATS, FEAT>(S, st, active, ray, 0u, R.max_depth, qo, cnt, R.use_rng != 0u);
+                c = trace_chain<STATS, FEAT>(S, st, active, ray, 0u, R.max_depth, qo, cnt, !PLAIN && R.use_rng != 0u);
             }
             if (STATS) { unsigned dn = cnt.node - node_before; if (dn > cnt.max_chain_nodes) cnt.max_chain_nodes = dn; }
             tot.x = tot.x + c.x; tot.y = tot.y + c.y; tot.z = tot.z + c.z;
         }
         if (active) {
             float* o = out + (size_t)pix * 3;
-            if (R.first_batch) { o[0] = tot.x; o[1] = tot.y; o[2] = tot.z; }
+            if (PLAIN || R.first_batch) { o[0] = tot.x; o[1] = tot.y; o[2] = tot.z; }
             else { o[0] += tot.x; o[1] += tot.y; o[2] += tot.z; }
-        } else if (i < R.width && rl < R.rows_local && R.first_batch) { // padding rows of the last band
+        } else if (i < R.width && rl < R.rows_local && (PLAIN || R.first_batch)) { // padding rows of the last band
             float* o = out + (size_t)pix * 3;
             o[0] = 0.0f; o[1] = 0.0f; o[2] = 0.0f;
         }
@@ -427,6 +428,14 @@ static void launch_primary(bool instrumented, int features, uint32_t grid, hipSt
                            uint32_t* zero_counts, DeviceCounters* zero_ctr) {
 #define NR_LAUNCH(F) hipLaunchKernelGGL((k_primary<false, F>), dim3(grid), dim3(kBlock), 0, stream, d, R, qo, out, ctr, spill, tx, ty, work, grab, zero_counts, zero_ctr)
     if (instrumented) { hipLaunchKernelGGL((k_primary<true, kFeatAll>), dim3(grid), dim3(kBlock), 0, stream, d, R, qo, out, ctr, spill, tx, ty, work, grab, zero_counts, zero_ctr); return; }
+    // plain frames (tables, no RNG keys, one sample per pixel) of the analytic-only permutations
+    const bool plain = R.col_tab && !R.use_rng && R.first_batch && R.sample_begin == 0u && R.sample_end == 1u;
+#define NR_LAUNCH_PLAIN(F) hipLaunchKernelGGL((k_primary<false, F, true>), dim3(grid), dim3(kBlock), 0, stream, d, R, qo, out, ctr, spill, tx, ty, work, grab, zero_counts, zero_ctr)
+    if (plain && features == 1) { NR_LAUNCH_PLAIN(1); return; }
+    if (plain && features == 5) { NR_LAUNCH_PLAIN(5); return; }
+    if (plain && features == 17) { NR_LAUNCH_PLAIN(17); return; }
+    if (plain && features == 21) { NR_LAUNCH_PLAIN(21); return; }
+#undef NR_LAUNCH_PLAIN
     switch (features) { // bit 8 (double branching) only in the full kernels; bit 16 = multi-sample lighting
     case 1: NR_LAUNCH(1); break;
     case 2: NR_LAUNCH(2); break;

@@ -1082,7 +1082,22 @@ NR_DEV f3 trace_chain(const DScene& S, Stack& st, bool alive, RayState ray, uint
 }
 
 // scene.rs:74-89: jitter, NDC, unproject by (P V)^-1, normalise.
+// PLAIN: a frame known (on the host) to use the raygen tables and no RNG keys — one sample per pixel, no AA jitter,
+// no area light; the generic code and the uniforms it needs drop out of the kernel.
+template <bool PLAIN = false>
 NR_DEV void generate_primary(const DRender& R, uint32_t i, uint32_t j, uint32_t s, uint32_t pixel_out, RayState& ray) {
+    if (PLAIN) {
+        const double* ct = R.col_tab + 4 * (size_t)i;
+        const double* rt = R.row_tab + 4 * (size_t)j;
+        double h[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[r] = ct[r] + rt[r] + R.m[8 + r] * -1.0 + R.m[12 + r] * 1.0;
+        d3 eye = D3(h[0] / h[3], h[1] / h[3], h[2] / h[3]);
+        d3 e0 = D3(R.eye[0], R.eye[1], R.eye[2]);
+        ray.o = e0; ray.d = normalize(eye - e0); ray.refr = 1.0; ray.energy = 1.0f; ray.weight = 1.0f;
+        ray.key = 0ULL; ray.pixel = pixel_out;
+        return;
+    }
     unsigned long long skey = 0;
     if (R.use_rng) { // keys are only ever consumed by AA jitter and area-light sampling
         unsigned long long pix = (unsigned long long)i + (unsigned long long)j * R.width;
