@@ -99,8 +99,12 @@ constexpr int waves_per_simd(int feat) { return (feat & ~kFeatMultiSample) == kF
 
 template <bool STATS, int FEAT, bool PLAIN = false>
 __global__ void __launch_bounds__(kBlock, waves_per_simd(FEAT)) k_primary(DScene S, DRender R, QueueOut qo, float* __restrict__ out, DeviceCounters* ctr,
-                                                     uint32_t* spill, uint32_t tiles_x, uint32_t tiles_y, uint32_t* work_counters, uint32_t grab,
+                                                     uint32_t* spill, uint32_t tiles_x, uint32_t tiles_y, uint32_t* work_counters, uint32_t grab_arg,
                                                      uint32_t* zero_counts, DeviceCounters* zero_ctr) {
+    // The scheduling path is fixed by the permutation — workgroup lists (0) for analytic-only scenes, XCD-aware HBM
+    // dequeue (>= 1) for scenes with meshes — so that each kernel carries one of them; only the full-featured kernels
+    // (instrumented renders, double branching) take it from the host at run time.
+    const uint32_t grab = (FEAT == kFeatAll || FEAT == 15) ? grab_arg : ((FEAT & kFeatMesh) ? (grab_arg ? grab_arg : 1u) : 0u);
     __shared__ uint32_t lds_stack[kLdsStack * kBlock];
     __shared__ uint32_t block_next; // grab == 0: next entry of this workgroup's tile list
     if (grab == 0u) { // workgroup-uniform
@@ -494,8 +498,8 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
 
     const uint32_t tiles_x = (p->width + kTile - 1) / kTile, tiles_y = (rows + kTile - 1) / kTile;
     const uint32_t ntiles = tiles_x * tiles_y;
-    uint32_t grab = (sc->features & kFeatMesh) ? 1u : 0u; // 0 = static wave-interleaved assignment
-    if (const char* e = getenv("NRAYS_GRAB")) grab = (uint32_t)std::max(0, atoi(e)); // scheduling A/B override (tools/kbench.py); pixels do not depend on it
+    uint32_t grab = sc->host.any_mesh ? 1u : 0u; // 0 = workgroup lists through LDS; the specialised kernels fix their path at compile time
+    if (const char* e = getenv("NRAYS_GRAB")) grab = (uint32_t)std::max(0, atoi(e)); // tiles per dequeue of the mesh kernels, A/B only (tools/kbench.py); pixels do not depend on it
     // persistent grid: exactly the workgroups that can be resident (one 4-wave workgroup per CU per wave/SIMD)
     const uint32_t grid_primary = std::min<uint32_t>(std::min<uint32_t>(((ntiles + 7u) / 8u) * 8u, (uint32_t)kMaxGrid),
                                                      (uint32_t)sc->num_cus * (uint32_t)waves_per_simd(instrumented ? kFeatAll : sc->features) * 256u / (uint32_t)kBlock);

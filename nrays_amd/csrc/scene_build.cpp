@@ -391,6 +391,7 @@ int build_host_scene(const NraysSceneDesc* d, HostScene& out, std::string& err) 
             if (!info[i].opaque) f |= 4;
         }
         if (f == 4 || f == 0) f |= 1; // empty scenes take the lightest kernel
+        out.any_mesh = (f & 2) != 0;
         if (out.any_double_branch) f = 15; // reflection + refraction at one hit: full kernel with the HBM queue
         if (!(d->num_lights == 1 && d->lights[0].racsample == 1)) f |= 16; // more than one light sample per hit
         out.features = f;
