@@ -439,6 +439,10 @@ static void launch_primary(bool instrumented, int features, uint32_t grid, hipSt
     if (plain && features == 5) { NR_LAUNCH_PLAIN(5); return; }
     if (plain && features == 17) { NR_LAUNCH_PLAIN(17); return; }
     if (plain && features == 21) { NR_LAUNCH_PLAIN(21); return; }
+    if (plain && features == 2) { NR_LAUNCH_PLAIN(2); return; }
+    if (plain && features == 6) { NR_LAUNCH_PLAIN(6); return; }
+    if (plain && features == 18) { NR_LAUNCH_PLAIN(18); return; }
+    if (plain && features == 22) { NR_LAUNCH_PLAIN(22); return; }
 #undef NR_LAUNCH_PLAIN
     switch (features) { // bit 8 (double branching) only in the full kernels; bit 16 = multi-sample lighting
     case 1: NR_LAUNCH(1); break;
