@@ -1,0 +1,51 @@
+#!/usr/bin/env python
+"""Soak run (GPU box): many frames per scene handle, alternating resolutions / cameras / sample counts, checking that
+every repeat of a configuration reproduces its first image bit for bit, that statistics stay constant and that
+device memory does not grow.  Exit code 1 on any deviation."""
+import ctypes as C, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+import torch
+import nrays_amd as nr
+from nrays_amd import abi
+from tests import scenes_util as su, standins
+lib = abi.load_hip_lib()
+
+def soak(name, sc, cam, configs, rounds):
+    ref = {}
+    bad = 0
+    free0 = None
+    t0 = time.time()
+    n = 0
+    outs = [torch.empty((h, w, 3), dtype=torch.float32, device="cuda") for (w, h, _) in configs]  # no allocator traffic in the loop
+    for r in range(rounds):
+        for ci, (w, h, kw) in enumerate(configs):
+            p, _ = su.camera_params(cam if "cam" not in kw else kw["cam"], w, h, **{k: v for k, v in kw.items() if k != "cam"})
+            out = outs[ci]
+            abi.check(lib.nrays_render_device(sc.device_handle(), C.byref(p), C.c_void_p(out.data_ptr()), None))
+            n += 1
+            if r % 50 == 0 or r == rounds - 1:
+                st = nr.get_stats(sc)
+                key = (ci,)
+                sig = (out.double().sum().item(), st.total_rays())
+                if key not in ref:
+                    ref[key] = (out.clone(), sig)
+                else:
+                    if not torch.equal(out, ref[key][0]) or sig != ref[key][1]:
+                        bad += 1
+                        print("DEVIATION", name, "config", ci, "round", r, sig, ref[key][1])
+        if r == 2:
+            free0 = torch.cuda.mem_get_info()[0]
+    free1 = torch.cuda.mem_get_info()[0]
+    leak = (free0 - free1) if free0 is not None else 0
+    print("%s: %d frames in %.1f s, deviations %d, device memory drift %d bytes" % (name, n, time.time() - t0, bad, leak), flush=True)
+    return bad + (1 if leak > (8 << 20) else 0)
+
+bad = 0
+sc, cam = su.balls_scene()
+bad += soak("balls", sc, cam, [(1920, 1080, {}), (640, 360, {}), (333, 77, dict(spp=4, window=1.0, seed=3)),
+                               (640, 360, dict(cam=dict(cam, eye=(2.0, 4.0, -9.0))))], 1500)
+sc, cam = su.primitives_scene()
+bad += soak("primitives", sc, cam, [(800, 600, {}), (320, 240, dict(spp=2, window=1.0, seed=1))], 300)
+sc, cam = standins.sponza_scene()
+bad += soak("sponza", sc, cam, [(1920, 1080, {}), (480, 270, {}), (480, 270, dict(max_depth=2))], 150)
+sys.exit(1 if bad else 0)
