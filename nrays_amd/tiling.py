@@ -89,6 +89,7 @@ class FramePipeline:
         if world > 1 and rank == 0:
             self.gathered = [torch.empty((world,) + tuple(tiles[0].shape), dtype=tiles[0].dtype, device=tiles[0].device)
                              for _ in range(2)]
+            self.gather_lists = [list(g.unbind(0)) for g in self.gathered]  # built once, not per step
         self.pending = None  # (work, slot, frame index)
         self.k = 0
 
@@ -110,7 +111,7 @@ class FramePipeline:
         work = None
         if self.world > 1:
             if self.rank == 0:
-                work = dist.gather(self.tiles[slot], gather_list=list(self.gathered[slot].unbind(0)), dst=0,
+                work = dist.gather(self.tiles[slot], gather_list=self.gather_lists[slot], dst=0,
                                    group=self.group, async_op=True)
             else:
                 work = dist.gather(self.tiles[slot], gather_list=None, dst=0, group=self.group, async_op=True)
