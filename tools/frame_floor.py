@@ -1,3 +1,5 @@
+"""Where a cheap analytic frame spends its time (GPU box): empty scene, all-miss scene, balls with and without
+reflection / depth cap, then empty and balls frames over a range of resolutions (fixed launch cost vs per-pixel cost)."""
 import ctypes as C, sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import torch
