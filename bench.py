@@ -211,7 +211,13 @@ def cpu_baseline(scene, params, budget_s):
             reps, params.width, params.height, rays, dt, cores, dt * cores)
     else:
         sample = "1/16 of the frame (every 16th 16-row band), %d rays, %.2f s" % (st.total_rays(), t_probe)
-    return {"value": round(rate / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port", "sample": sample}
+    rays = max(st.total_rays(), 1)
+    # the same rays through the reference-equivalent tree (median split, one primitive per leaf, best-first
+    # search), reported beside the shipped BVH's counts in roofline.units_per_launch
+    ref_counts = {"aabb_tests_per_ray": round(st.node_tests / rays, 2), "tri_tests_per_ray": round(st.tri_tests / rays, 2),
+                  "prim_tests_per_ray": round(st.prim_tests / rays, 3)}
+    return {"value": round(rate / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port", "sample": sample,
+            "reference_tree_counts": ref_counts}
 
 
 if __name__ == "__main__":
