@@ -1,12 +1,16 @@
 // nrays_hip.hip — gfx950 kernels and the C-ABI entry points of include/nrays_abi.h.
 //
 // Launch structure of one nrays_render (replaces scene::render, src/scene.rs:29-116):
-//   k_primary   one lane per pixel of a 16x16 tile (one 8x8 sub-tile per wave64), looping over the
-//               AA samples of the batch: raygen -> closest hit -> Phong + shadow rays -> pixel
-//               accumulation; reflection / refraction continuations are compacted with wave ballots
-//               into the generation-1 queue.  Persistent grid, XCD-aware tile order.
-//   k_bounce    generation g: grid-stride over the compacted queue, same per-ray work, atomicAdd of the
-//               weighted contribution into the pixel, continuations appended to generation g+1.
+//   k_raygen_tables  only when the camera or the resolution of a jitter-free frame changed: per-column / per-row
+//               products of the unprojection (a few microseconds, cached on the scene handle).
+//   k_tile_order     mesh scenes, from the second frame of a geometry on: wave tiles sorted by the previous frame's
+//               per-tile cost (8 LDS counting sorts), so that the deep chains start first.
+//   k_primary   persistent grid; one lane per pixel of an 8x8 wave tile, looping over the AA samples of the batch:
+//               raygen -> [no ray of the tile passes the root box: background] -> closest hit -> Phong + shadow
+//               rays -> continuation kept in registers (trace_chain) -> pixel write.  Only the second child of a
+//               hit that spawns a reflection AND a refraction goes to the compacted HBM queue (wave ballots).
+//   k_bounce    rounds over that queue (double-branching scenes only): same per-ray work, atomicAdd of the weighted
+//               contribution into the pixel, second children appended to the next round's queue.
 //   k_resolve   divides by ray_per_pixel when it is > 1 (scene.rs:94).
 //   k_untile    un-permutes gathered multi-GPU tile buffers.
 #include <hip/hip_runtime.h>
@@ -29,29 +33,28 @@ namespace nrays {
 #ifndef NRAYS_WAVES_PER_SIMD
 #define NRAYS_WAVES_PER_SIMD 2 // second __launch_bounds__ argument: caps the VGPR budget at 512 / this
 #endif
-constexpr int kTile = 16;          // a workgroup renders a 16x16 pixel tile
+constexpr int kTile = 16;          // four consecutive 8x8 wave tiles form a 16x16 pixel block
 constexpr int kNumCounts = kMaxGenerations + 2 + 8; // queue round counters + 8 per-XCD work counters
-constexpr int kMaxGrid = 2048;     // persistent grid: 256 CUs x 8 workgroups
+constexpr int kMaxGrid = 2048;     // upper bound of the persistent grid (the launch uses CUs x waves/SIMD workgroups)
 
-// XCD-aware dynamic scheduling of the persistent grid.  The tiles (in row-major order) are cut into 8
-// contiguous ranges, one per XCD, each with its own work counter in HBM.  A workgroup reads the id
-// of the XCD it runs on and pulls tiles from that XCD's range — so one XCD's private 4 MiB L2 keeps
-// seeing the same region of the image and of the BVH — and when the range is exhausted it steals
-// from the next XCD's range, which removes the tail of a static split (ball / foliage pixels cost
-// 5-10x a sky pixel).  Placement only affects speed: any assignment yields the same pixels.
+// XCD-aware dynamic scheduling of the persistent grid (scenes with meshes; analytic-only scenes use per-workgroup
+// lists through an LDS counter, see k_primary).  Every XCD owns a work list with its own counter in HBM: without
+// history a contiguous range of the image — so one XCD's private 4 MiB L2 keeps seeing the same region of the image
+// and of the BVH — with history every 8th entry of the cost-sorted order.  A wave reads the id of the XCD it runs
+// on, pulls from that XCD's list and, when it is exhausted, steals from the next one, which removes the tail of a
+// static split (foliage pixels cost 10x+ a wall pixel).  Placement only affects speed: any assignment yields the
+// same pixels.
 __device__ __forceinline__ uint32_t xcc_id() {
     uint32_t v;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
     return v & 7u;
 }
-// Per-WAVE dequeue of 8x8-pixel wave tiles: lane 0 pulls, the index is broadcast through an SGPR;
-// no workgroup barrier is involved, so a wave that drew cheap (sky) tiles never waits for a sibling
-// that drew expensive ones.  The atomic for the NEXT grab is issued before the current tiles are
-// traced, so its ~1 us latency hides behind the work.  Wave tiles are numbered so that four
-// consecutive ones form a 16x16 pixel block.
-// `grab` (wave tiles per atomic) is chosen per scene on the host: analytic-only scenes have ~5 us tiles
-// and are bound by atomic throughput (large, prefetched grabs); mesh scenes have tiles whose cost
-// varies 10x+ and are bound by the tail (one tile per grab, no reserve-ahead).
+// Per-WAVE dequeue of 8x8-pixel wave tiles: lane 0 pulls, the index is broadcast through an SGPR; no workgroup
+// barrier is involved, so a wave that drew cheap tiles never waits for a sibling that drew expensive ones.  The
+// atomic for the NEXT grab is issued before the current tile is traced, so its latency hides behind the work
+// (device-scope atomics on one address retire at only ~9 M/s on this part: fine for 50+ us mesh tiles, useless for
+// the ~1 us tiles of analytic scenes).  Wave tiles are numbered so that four consecutive ones form a 16x16 block.
+// `grab` = wave tiles per atomic (1; NRAYS_GRAB overrides it for A/B runs).
 __device__ __forceinline__ uint32_t issue_grab(uint32_t* work_counters, uint32_t victim, uint32_t grab) {
     uint32_t k = 0;
     if (__lane_id() == 0) k = atomicAdd(&work_counters[victim], grab);

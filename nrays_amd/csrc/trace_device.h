@@ -1,6 +1,7 @@
 // trace_device.h — gfx950 device code of the nrays trace loop: ray/shape intersectors, two-level
-// BVH traversal with an LDS-resident stack, Phong shading with shadow rays, continuation-ray
-// emission through wave ballot + prefix-sum compaction.
+// BVH traversal with an LDS-resident stack, Phong shading with shadow rays, the reflection / refraction
+// recursion as an in-register bounce loop (second children of double branches: wave ballot + prefix-sum
+// compaction into an HBM queue).
 //
 // Reference functions replaced:
 //   a1  render pixel/AA loop               src/scene.rs:67-95          -> generate_primary()
@@ -8,7 +9,7 @@
 //   a5  SceneNode::cast + ncollide shapes  src/scene_node.rs:51-54     -> cast_*()
 //   a6  ray/triangle                       ncollide (SURVEY B-8)       -> cast_triangle()
 //   a7  TransparentShadowsRayTOICostFn     src/scene.rs:147-161,285-339-> traverse<true>()
-//   a8-a10 Scene::trace / reflection / refraction  src/scene.rs:163-252-> shade_and_continue()
+//   a8-a10 Scene::trace / reflection / refraction  src/scene.rs:163-252-> shade_hit(), trace_chain()
 //   a11 PhongMaterial                      src/phong_material.rs:39-151-> material_*()
 //   a12 Light::sample                      src/light.rs:57-63          -> light loop in material_compute()
 //   a13 Texture2d::sample                  src/texture2d.rs:203-256    -> tex_sample()
