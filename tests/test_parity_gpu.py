@@ -303,3 +303,36 @@ def test_randomised_scenes_sweep(gpu):
                        stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:]
     assert "0 mismatches" in r.stdout
+
+
+def test_distinct_scenes_render_concurrently_from_two_threads(gpu):
+    """SURVEY 8b threading contract: the library is re-entrant on distinct scene handles (each call on its own
+    HIP stream, from its own host thread); the frames must equal the ones rendered alone."""
+    import threading
+    import torch
+    lib = abi.load_hip_lib()
+    sa, ca = su.balls_scene(tex_size=(64, 32))
+    sb, cb = su.mesh_scene()
+    pa, _ = su.camera_params(ca, 320, 200)
+    pb, _ = su.camera_params(cb, 240, 160)
+    alone_a, _ = hip_render(sa, pa)
+    alone_b, _ = hip_render(sb, pb)
+    results, errors = {}, []
+
+    def worker(name, scene, params, shape):
+        try:
+            stream = torch.cuda.Stream()
+            out = torch.empty(shape, dtype=torch.float32, device="cuda")
+            for _ in range(40):
+                abi.check(lib.nrays_render_device(scene.device_handle(), C.byref(params), C.c_void_p(out.data_ptr()),
+                                                  C.c_void_p(stream.cuda_stream)))
+            stream.synchronize()
+            results[name] = out.cpu().numpy()
+        except Exception as e:  # pragma: no cover - reported below
+            errors.append((name, repr(e)))
+
+    ta = threading.Thread(target=worker, args=("a", sa, pa, (200, 320, 3)))
+    tb = threading.Thread(target=worker, args=("b", sb, pb, (160, 240, 3)))
+    ta.start(); tb.start(); ta.join(); tb.join()
+    assert not errors, errors
+    assert np.array_equal(results["a"], alone_a) and np.array_equal(results["b"], alone_b)
