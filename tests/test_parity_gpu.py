@@ -336,3 +336,28 @@ def test_distinct_scenes_render_concurrently_from_two_threads(gpu):
     ta.start(); tb.start(); ta.join(); tb.join()
     assert not errors, errors
     assert np.array_equal(results["a"], alone_a) and np.array_equal(results["b"], alone_b)
+
+
+def test_long_thin_diagonal_triangles(gpu):
+    """Needle field: hundreds of long, thin, randomly oriented triangles — the references the BLAS builder pre-splits
+    (their boxes are almost empty).  Every piece box must still lead to the whole triangle: pixels and ray counts
+    equal to the oracle, for a rotated and an unrotated node, with reflections bouncing between the needles."""
+    rng = np.random.default_rng(77)
+    nt = 600
+    a = rng.uniform(-4, 4, (nt, 3))
+    d = rng.normal(size=(nt, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    q = np.cross(d, rng.normal(size=(nt, 3))); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    length = rng.uniform(2.0, 7.0, (nt, 1)); width = rng.uniform(0.01, 0.15, (nt, 1))
+    tri = su.f32_exact(np.stack([a, a + d * length, a + d * length * 0.5 + q * width], axis=1).reshape(-1, 3))
+    idx = np.arange(3 * nt, dtype=np.uint32).reshape(nt, 3)
+    uvs = su.f32_exact(rng.uniform(0, 1, (3 * nt, 2)))
+    mat = nr.PhongMaterial((0.1, 0.1, 0.1), (0.9, 0.6, 0.3), (1, 1, 1), su.checker_texture(32, 4), None, 40.0)
+    half = 3 * (nt // 2)
+    nodes = [nr.SceneNode(mat, 0.3, 0.4, 1.0, 1.0, nr.Isometry3((0, 0, 0)), nr.TriMesh(tri[:half], idx[:nt // 2], uvs[:half])),
+             nr.SceneNode(su.default_material(), 0.0, 0.0, 1.0, 1.0, nr.Isometry3((0.3, -0.2, 0.1), (0.2, 0.7, -0.4)),
+                          nr.TriMesh(tri[half:], idx[:nt - nt // 2], uvs[half:]))]
+    sc = nr.Scene(nodes, [nr.Light((3.0, 9.0, -6.0), 0.0, 1, (1, 1, 1)), nr.Light((-5.0, 4.0, -8.0), 0.0, 1, (0.4, 0.4, 0.6))], (0.2, 0.3, 0.4))
+    cam = dict(eye=(1.0, 2.0, -13.0), at=(0.0, 0.0, 0.0), fovy=45.0)
+    _, _, st, _ = compare(sc, cam, 400, 300)
+    assert st.rays_shadow > 0 and st.rays_reflection > 0
+    compare(sc, dict(cam, eye=(-9.0, -3.0, 6.0)), 233, 171)
