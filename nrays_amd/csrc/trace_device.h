@@ -782,10 +782,14 @@ NR_DEV bool traverse(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, Hit&
         uint32_t lv = (uint32_t)~cur;
         uint32_t first = lv >> 3, bits = lv & 7u;
         if (kMesh && in_blas) { // triangle leaf
+            // the record of triangle k + 1 is fetched while triangle k is tested (a wave alone on its SIMD in the deep
+            // tail of a frame otherwise pays a full memory round trip per triangle)
+            const float4* tq = (const float4*)(S.tris + first);
+            float4 p0 = tq[0], p1 = tq[1], p2 = tq[2];
 #pragma nounroll
             for (uint32_t k = 0; k <= bits; ++k) {
-                const float4* tq = (const float4*)(S.tris + first + k);
-                float4 t0 = tq[0], t1 = tq[1], t2 = tq[2];
+                const float4 t0 = p0, t1 = p1, t2 = p2;
+                if (k < bits) { tq += 3; p0 = tq[0]; p1 = tq[1]; p2 = tq[2]; }
                 if (STATS) cnt.tri++;
                 double toi;
                 d3 va = D3(t0.x, t0.y, t0.z), vb = D3(t1.x, t1.y, t1.z), vc = D3(t2.x, t2.y, t2.z);
