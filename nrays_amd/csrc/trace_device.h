@@ -786,6 +786,7 @@ NR_DEV bool traverse(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, Hit&
             // tail of a frame otherwise pays a full memory round trip per triangle)
             const float4* tq = (const float4*)(S.tris + first);
             float4 p0 = tq[0], p1 = tq[1], p2 = tq[2];
+            const int32_t after_leaf = st.sp ? st.pop() : kEmptyChild; // popped now: the LDS latency hides behind the tests
 #pragma nounroll
             for (uint32_t k = 0; k <= bits; ++k) {
                 const float4 t0 = p0, t1 = p1, t2 = p2;
@@ -803,7 +804,7 @@ NR_DEV bool traverse(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, Hit&
                     }
                 }
             }
-            cur = st.sp ? st.pop() : kEmptyChild;
+            cur = after_leaf;
             continue;
         }
         if (kMesh && (!kAnalytic || (bits & kLeafMesh))) { // TLAS leaf: a BLAS
