@@ -135,7 +135,8 @@ struct Blas {
 // gates are unchanged, a triangle reached through two references is simply found twice with the same
 // (toi, node, triangle) key.  Measured (MI355X, 1080p): budget 1 / min gain 0.5: hairball 5.94 -> 4.57 ms (54 -> 27
 // triangle tests per ray), sponza 1.85 -> 1.81 ms, +3.6 s of scene build on 2.88 M triangles; budget 2 / 0.2: hairball
-// 4.22 ms but sponza +1 %; budget 3 / 0.1: hairball 3.96 ms, sponza +6 %, build +20 s.
+// 4.22 ms but sponza +1 %; budget 3 / 0.1: hairball 3.96 ms, sponza +6 %, build +20 s — hence the per-mesh choice
+// below: the aggressive setting only for hair-like meshes (hairball 4.20 -> 3.71 ms on top of the later leaf-loop work).
 #ifndef NR_PRESPLIT_BUDGET
 #define NR_PRESPLIT_BUDGET 1.0  // at most this many extra references per triangle on average
 #endif
@@ -200,12 +201,32 @@ static double poly_area2(const ClipPoly& p) { // twice the area of a planar conv
 #ifndef NR_PRESPLIT_EMPTY
 #define NR_PRESPLIT_EMPTY 0.5
 #endif
+#ifndef NR_PRESPLIT_HAIRY
+#define NR_PRESPLIT_HAIRY 0.9        // area-weighted emptiness of the mesh above which it counts as hair-like
+#endif
+#ifndef NR_PRESPLIT_BUDGET_HAIRY
+#define NR_PRESPLIT_BUDGET_HAIRY 3.0
+#endif
+#ifndef NR_PRESPLIT_MINGAIN_HAIRY
+#define NR_PRESPLIT_MINGAIN_HAIRY 0.1
+#endif
 static void presplit(const std::vector<TriRec>& recs, std::vector<PrimBounds>& refs_box, std::vector<uint32_t>& refs_tri) {
     const size_t n = recs.size();
     if (n < 64 || NR_PRESPLIT_BUDGET <= 0.0) return;
     double total_area = 0.0;
     for (size_t i = 0; i < n; ++i) total_area += box_half_area(refs_box[i]);
-    const double min_gain = NR_PRESPLIT_MINGAIN * total_area / (double)n;
+    // Hair-like meshes (most triangles are thin and diagonal: the average box is more than NR_PRESPLIT_HAIRY empty)
+    // get the aggressive setting; architectural meshes, where only a few curved parts qualify, the mild one.
+    double total_tri2 = 0.0;
+    for (size_t i = 0; i < n; ++i) {
+        ClipPoly p; p.n = 3;
+        const float* vs[3] = {recs[i].v0, recs[i].v1, recs[i].v2};
+        for (int k = 0; k < 3; ++k) for (int d = 0; d < 3; ++d) p.v[k][d] = vs[k][d];
+        total_tri2 += poly_area2(p);
+    }
+    const bool hairy = total_area > 0.0 && (total_area - total_tri2) > NR_PRESPLIT_HAIRY * total_area;
+    const double budget_per_tri = hairy ? NR_PRESPLIT_BUDGET_HAIRY : NR_PRESPLIT_BUDGET;
+    const double min_gain = (hairy ? NR_PRESPLIT_MINGAIN_HAIRY : NR_PRESPLIT_MINGAIN) * total_area / (double)n;
     struct Cand { double gain; uint32_t ref; uint32_t poly; };
     auto cmp = [](const Cand& a, const Cand& b) { return a.gain < b.gain; };
     std::vector<Cand> heap;
@@ -223,7 +244,7 @@ static void presplit(const std::vector<TriRec>& recs, std::vector<PrimBounds>& r
         polys.push_back(p);
         if (!consider((uint32_t)i, (uint32_t)polys.size() - 1)) polys.pop_back();
     }
-    size_t budget = (size_t)(NR_PRESPLIT_BUDGET * (double)n);
+    size_t budget = (size_t)(budget_per_tri * (double)n);
     while (budget > 0 && !heap.empty()) {
         std::pop_heap(heap.begin(), heap.end(), cmp);
         const Cand c = heap.back(); heap.pop_back();
