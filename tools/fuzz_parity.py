@@ -57,7 +57,7 @@ def random_mesh_scene(seed):
     amap = [su.checker_texture(32, 6, alpha_holes=True), None, None]
     nodes, prev = [], None
     for k in range(int(rng.integers(2, 7))):
-        nt = int(rng.integers(4, 200))
+        nt = int(rng.integers(4, 500))  # >= 64 triangles in a BLAS: the pre-splitting pass is active
         ctr = rng.uniform(-4, 4, (nt, 1, 3)) * np.array([1.0, 0.6, 1.0])
         tri = su.f32_exact((ctr + rng.normal(0, float(rng.choice([0.2, 0.8, 2.0])), (nt, 3, 3))).reshape(-1, 3))
         if rng.random() < 0.2:
