@@ -2,6 +2,9 @@
 #include "scene_build.h"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <cstring>
 #include <limits>
@@ -245,6 +248,8 @@ static void presplit(const std::vector<TriRec>& recs, std::vector<PrimBounds>& r
         if (!consider((uint32_t)i, (uint32_t)polys.size() - 1)) polys.pop_back();
     }
     size_t budget = (size_t)(budget_per_tri * (double)n);
+    refs_box.reserve(n + budget); refs_tri.reserve(n + budget); // no reallocation (and page-fault) churn while splitting
+    polys.reserve(polys.size() + budget); heap.reserve(heap.size() + budget);
     while (budget > 0 && !heap.empty()) {
         std::pop_heap(heap.begin(), heap.end(), cmp);
         const Cand c = heap.back(); heap.pop_back();
@@ -315,8 +320,12 @@ int append_blas(const NraysSceneDesc* d, const std::vector<uint32_t>& node_ids, 
 #endif
     std::vector<uint32_t> ref_tri(recs.size());
     for (size_t k = 0; k < ref_tri.size(); ++k) ref_tri[k] = (uint32_t)k;
+    auto T0 = std::chrono::steady_clock::now();
     presplit(recs, pb, ref_tri); // pb becomes one box per REFERENCE
+    auto T1 = std::chrono::steady_clock::now();
     BuiltBvh bvh = build_bvh(pb, NR_MAX_LEAF);
+    auto T2 = std::chrono::steady_clock::now();
+    if (getenv("NRAYS_BUILD_TIMES")) fprintf(stderr, "presplit %.2f s, build_bvh %.2f s (%zu refs)\n", std::chrono::duration<double>(T1 - T0).count(), std::chrono::duration<double>(T2 - T1).count(), pb.size());
     if (out.tris.size() + pb.size() >= (1u << 28)) { err = "too many triangles"; return NRAYS_ERR_UNSUPPORTED; }
     rebase_bvh(bvh, (int32_t)out.nodes.size(), (uint32_t)out.tris.size());
     out.max_bvh_depth = std::max(out.max_bvh_depth, bvh.max_depth);
