@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <future>
 #include <limits>
 
 namespace nrays {
@@ -48,23 +49,35 @@ struct Node2 { // binary node produced by the SAH build, collapsed into 4-wide B
     int32_t left, right;
 };
 
+// Large subtrees of the top `kParLevels` levels are built by their own thread into a local node array and
+// spliced into the parent's array afterwards (child indices shifted by the splice offset): the tree is the one the
+// sequential build produces, only the order of the nodes in memory differs.  The partition step works on disjoint
+// ranges of `order`, everything else a task touches is read-only or its own.
+constexpr int kParLevels = 6;          // up to 64 concurrent subtrees
+constexpr uint32_t kParMinCount = 100000;
+
 struct Builder {
     const std::vector<PrimBounds>& prims;
     std::vector<uint32_t>& order;
     std::vector<Node2>& nodes;
-    std::vector<float> cent; // 3 per prim
+    const std::vector<float>* cent_ptr; // 3 per prim (owned by the root builder)
+    std::vector<float> cent_own;
     int max_leaf;
     int max_depth = 0;
 
     Builder(const std::vector<PrimBounds>& p, std::vector<uint32_t>& o, std::vector<Node2>& n, int ml)
         : prims(p), order(o), nodes(n), max_leaf(ml) {
-        cent.resize(p.size() * 3);
+        cent_own.resize(p.size() * 3);
         for (size_t i = 0; i < p.size(); ++i)
-            for (int a = 0; a < 3; ++a) cent[3 * i + a] = 0.5f * p[i].mn[a] + 0.5f * p[i].mx[a];
+            for (int a = 0; a < 3; ++a) cent_own[3 * i + a] = 0.5f * p[i].mn[a] + 0.5f * p[i].mx[a];
+        cent_ptr = &cent_own;
     }
+    Builder(const Builder& parent, std::vector<Node2>& local) // a task's builder: shares everything but the node array
+        : prims(parent.prims), order(parent.order), nodes(local), cent_ptr(parent.cent_ptr), max_leaf(parent.max_leaf) {}
 
     // Builds the subtree over order[first, first+count); returns its ref and bounds.
     int32_t build(uint32_t first, uint32_t count, Box& bounds, int depth) {
+        const std::vector<float>& cent = *cent_ptr;
         max_depth = std::max(max_depth, depth);
         bounds.reset();
         Box cb; cb.reset();
@@ -125,8 +138,25 @@ struct Builder {
         int32_t me = (int32_t)nodes.size();
         nodes.emplace_back();
         Box lb, rb;
-        int32_t l = build(first, mid - first, lb, depth + 1);
-        int32_t r = build(mid, first + count - mid, rb, depth + 1);
+        int32_t l, r;
+        if (depth < kParLevels && mid - first >= kParMinCount && first + count - mid >= kParMinCount) {
+            std::vector<Node2> local;
+            Builder lbuilder(*this, local);
+            auto fut = std::async(std::launch::async, [&]() { return lbuilder.build(first, mid - first, lb, depth + 1); });
+            r = build(mid, first + count - mid, rb, depth + 1);
+            l = fut.get();
+            max_depth = std::max(max_depth, lbuilder.max_depth);
+            const int32_t off = (int32_t)nodes.size();
+            for (Node2 ln : local) {
+                if (ln.left >= 0) ln.left += off;
+                if (ln.right >= 0) ln.right += off;
+                nodes.push_back(ln);
+            }
+            if (l >= 0) l += off;
+        } else {
+            l = build(first, mid - first, lb, depth + 1);
+            r = build(mid, first + count - mid, rb, depth + 1);
+        }
         Node2& n = nodes[me];
         for (int a = 0; a < 3; ++a) { n.lmin[a] = lb.mn[a]; n.lmax[a] = lb.mx[a]; n.rmin[a] = rb.mn[a]; n.rmax[a] = rb.mx[a]; }
         n.left = l; n.right = r;

@@ -3,6 +3,8 @@
 
 #include <algorithm>
 #include <chrono>
+#include <future>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cmath>
@@ -213,6 +215,76 @@ static double poly_area2(const ClipPoly& p) { // twice the area of a planar conv
 #ifndef NR_PRESPLIT_MINGAIN_HAIRY
 #define NR_PRESPLIT_MINGAIN_HAIRY 0.1
 #endif
+static void tri_poly(const TriRec& r, ClipPoly& p) {
+    p.n = 3;
+    const float* vs[3] = {r.v0, r.v1, r.v2};
+    for (int k = 0; k < 3; ++k) for (int d = 0; d < 3; ++d) p.v[k][d] = vs[k][d];
+}
+// One midpoint split of a piece; false if the piece cannot be split (degenerate clip, vertex budget, empty box).
+static bool split_piece(const ClipPoly& poly, const PrimBounds& box, ClipPoly& lo, ClipPoly& hi, PrimBounds& bl, PrimBounds& bh) {
+    int axis = 0; float ext = box.mx[0] - box.mn[0];
+    for (int a = 1; a < 3; ++a) if (box.mx[a] - box.mn[a] > ext) { ext = box.mx[a] - box.mn[a]; axis = a; }
+    const double mid = 0.5 * ((double)box.mn[axis] + (double)box.mx[axis]);
+    if (!clip_half(poly, axis, mid, true, lo) || !clip_half(poly, axis, mid, false, hi)) return false;
+    if (lo.n < 3 || hi.n < 3) return false; // the plane misses the piece (degenerate): leave it alone
+    bl = poly_box(lo, box); bh = poly_box(hi, box);
+    for (int a = 0; a < 3; ++a) if (!(bl.mn[a] <= bl.mx[a]) || !(bh.mn[a] <= bh.mx[a])) return false;
+    return true;
+}
+// The exact procedure: pieces split in order of decreasing empty area until the budget is used up.  `tris` lists the
+// triangles taking part (all of them, or a sample); boxes[k] / owner[k] describe reference k (k < tris.size(): the
+// k-th listed triangle).  Returns the empty area of the last piece split (the threshold the budget amounts to), or
+// `min_gain` when every candidate was split before the budget ran out.
+static double presplit_heap(const std::vector<TriRec>& recs, const std::vector<uint32_t>& tris, std::vector<PrimBounds>& boxes,
+                            std::vector<uint32_t>& owner, size_t budget, double min_gain) {
+    struct Cand { double gain; uint32_t ref; uint32_t poly; };
+    auto cmp = [](const Cand& a, const Cand& b) { return a.gain < b.gain; };
+    std::vector<Cand> heap;
+    std::vector<ClipPoly> polys; // pool; slots of split pieces are reused by their low halves
+    auto consider = [&](uint32_t ref, uint32_t poly_slot) {
+        const double ha = box_half_area(boxes[ref]);
+        const double gain = ha - poly_area2(polys[poly_slot]);
+        if (gain > min_gain && gain > NR_PRESPLIT_EMPTY * ha) { heap.push_back(Cand{gain, ref, poly_slot}); std::push_heap(heap.begin(), heap.end(), cmp); return true; }
+        return false;
+    };
+    for (size_t k = 0; k < tris.size(); ++k) {
+        ClipPoly p; tri_poly(recs[tris[k]], p);
+        polys.push_back(p);
+        if (!consider((uint32_t)k, (uint32_t)polys.size() - 1)) polys.pop_back();
+    }
+    double last = min_gain;
+    while (budget > 0 && !heap.empty()) {
+        std::pop_heap(heap.begin(), heap.end(), cmp);
+        const Cand c = heap.back(); heap.pop_back();
+        ClipPoly lo, hi; PrimBounds bl, bh;
+        if (!split_piece(polys[c.poly], boxes[c.ref], lo, hi, bl, bh)) continue;
+        last = c.gain;
+        boxes[c.ref] = bl;
+        const uint32_t ref_hi = (uint32_t)boxes.size();
+        boxes.push_back(bh); owner.push_back(owner[c.ref]);
+        polys[c.poly] = lo;
+        consider(c.ref, c.poly);
+        polys.push_back(hi);
+        if (!consider(ref_hi, (uint32_t)polys.size() - 1)) polys.pop_back();
+        --budget;
+    }
+    return heap.empty() ? min_gain : last;
+}
+// The same rule as a threshold: a piece is split while its empty area exceeds `thr` (children have less empty area than
+// their parent, so this is what the heap does once the threshold its budget amounts to is known) — no global state,
+// hence one task per range of triangles.
+struct SplitOut { std::vector<PrimBounds> box; std::vector<uint32_t> tri; };
+static void split_rec(const ClipPoly& poly, const PrimBounds& box, uint32_t tri, double thr, int depth, PrimBounds* root_slot, long slot, SplitOut& out) {
+    auto store = [&](const PrimBounds& b) { if (slot < 0) *root_slot = b; else out.box[(size_t)slot] = b; };
+    const double ha = box_half_area(box);
+    const double gain = ha - poly_area2(poly);
+    ClipPoly lo, hi; PrimBounds bl, bh;
+    if (depth >= 20 || !(gain > thr && gain > NR_PRESPLIT_EMPTY * ha) || !split_piece(poly, box, lo, hi, bl, bh)) { store(box); return; }
+    const long hi_slot = (long)out.box.size();
+    out.box.push_back(bh); out.tri.push_back(tri);
+    split_rec(lo, bl, tri, thr, depth + 1, root_slot, slot, out);
+    split_rec(hi, bh, tri, thr, depth + 1, root_slot, hi_slot, out);
+}
 static void presplit(const std::vector<TriRec>& recs, std::vector<PrimBounds>& refs_box, std::vector<uint32_t>& refs_tri) {
     const size_t n = recs.size();
     if (n < 64 || NR_PRESPLIT_BUDGET <= 0.0) return;
@@ -221,58 +293,43 @@ static void presplit(const std::vector<TriRec>& recs, std::vector<PrimBounds>& r
     // Hair-like meshes (most triangles are thin and diagonal: the average box is more than NR_PRESPLIT_HAIRY empty)
     // get the aggressive setting; architectural meshes, where only a few curved parts qualify, the mild one.
     double total_tri2 = 0.0;
-    for (size_t i = 0; i < n; ++i) {
-        ClipPoly p; p.n = 3;
-        const float* vs[3] = {recs[i].v0, recs[i].v1, recs[i].v2};
-        for (int k = 0; k < 3; ++k) for (int d = 0; d < 3; ++d) p.v[k][d] = vs[k][d];
-        total_tri2 += poly_area2(p);
-    }
+    for (size_t i = 0; i < n; ++i) { ClipPoly p; tri_poly(recs[i], p); total_tri2 += poly_area2(p); }
     const bool hairy = total_area > 0.0 && (total_area - total_tri2) > NR_PRESPLIT_HAIRY * total_area;
     const double budget_per_tri = hairy ? NR_PRESPLIT_BUDGET_HAIRY : NR_PRESPLIT_BUDGET;
     const double min_gain = (hairy ? NR_PRESPLIT_MINGAIN_HAIRY : NR_PRESPLIT_MINGAIN) * total_area / (double)n;
-    struct Cand { double gain; uint32_t ref; uint32_t poly; };
-    auto cmp = [](const Cand& a, const Cand& b) { return a.gain < b.gain; };
-    std::vector<Cand> heap;
-    std::vector<ClipPoly> polys; // pool; slots of split pieces are reused by their low halves
-    auto consider = [&](uint32_t ref, uint32_t poly_slot) {
-        const double ha = box_half_area(refs_box[ref]);
-        const double gain = ha - poly_area2(polys[poly_slot]);
-        if (gain > min_gain && gain > NR_PRESPLIT_EMPTY * ha) { heap.push_back(Cand{gain, ref, poly_slot}); std::push_heap(heap.begin(), heap.end(), cmp); return true; }
-        return false;
-    };
-    for (size_t i = 0; i < n; ++i) {
-        ClipPoly p; p.n = 3;
-        const float* vs[3] = {recs[i].v0, recs[i].v1, recs[i].v2};
-        for (int k = 0; k < 3; ++k) for (int d = 0; d < 3; ++d) p.v[k][d] = vs[k][d];
-        polys.push_back(p);
-        if (!consider((uint32_t)i, (uint32_t)polys.size() - 1)) polys.pop_back();
+    const size_t budget = (size_t)(budget_per_tri * (double)n);
+    constexpr size_t kExactBelow = 400000; // triangles: below this the heap runs on the whole mesh
+    if (n <= kExactBelow) {
+        std::vector<uint32_t> all(n);
+        for (size_t i = 0; i < n; ++i) all[i] = (uint32_t)i;
+        presplit_heap(recs, all, refs_box, refs_tri, budget, min_gain);
+        return;
     }
-    size_t budget = (size_t)(budget_per_tri * (double)n);
-    refs_box.reserve(n + budget); refs_tri.reserve(n + budget); // no reallocation (and page-fault) churn while splitting
-    polys.reserve(polys.size() + budget); heap.reserve(heap.size() + budget);
-    while (budget > 0 && !heap.empty()) {
-        std::pop_heap(heap.begin(), heap.end(), cmp);
-        const Cand c = heap.back(); heap.pop_back();
-        const PrimBounds box = refs_box[c.ref];
-        int axis = 0; float ext = box.mx[0] - box.mn[0];
-        for (int a = 1; a < 3; ++a) if (box.mx[a] - box.mn[a] > ext) { ext = box.mx[a] - box.mn[a]; axis = a; }
-        const double mid = 0.5 * ((double)box.mn[axis] + (double)box.mx[axis]);
-        ClipPoly lo, hi;
-        if (!clip_half(polys[c.poly], axis, mid, true, lo) || !clip_half(polys[c.poly], axis, mid, false, hi)) continue;
-        if (lo.n < 3 || hi.n < 3) continue; // the plane misses the piece (degenerate): leave it alone
-        PrimBounds bl = poly_box(lo, box), bh = poly_box(hi, box);
-        bool ok = true;
-        for (int a = 0; a < 3; ++a) if (!(bl.mn[a] <= bl.mx[a]) || !(bh.mn[a] <= bh.mx[a])) ok = false;
-        if (!ok) continue;
-        refs_box[c.ref] = bl;
-        const uint32_t ref_hi = (uint32_t)refs_box.size();
-        refs_box.push_back(bh); refs_tri.push_back(refs_tri[c.ref]);
-        polys[c.poly] = lo;
-        consider(c.ref, c.poly);
-        polys.push_back(hi);
-        if (!consider(ref_hi, (uint32_t)polys.size() - 1)) polys.pop_back();
-        --budget;
+    // Large meshes: the threshold is measured on every s-th triangle with 1/s of the budget, then all triangles are
+    // split against it in parallel.
+    const size_t stride = (n + kExactBelow / 4 - 1) / (kExactBelow / 4);
+    std::vector<uint32_t> sample; std::vector<PrimBounds> sbox; std::vector<uint32_t> sowner;
+    for (size_t i = 0; i < n; i += stride) { sample.push_back((uint32_t)i); sbox.push_back(refs_box[i]); sowner.push_back((uint32_t)i); }
+    const double thr = presplit_heap(recs, sample, sbox, sowner, budget / stride, min_gain);
+    const unsigned hw = std::thread::hardware_concurrency();
+    const size_t tasks = std::min<size_t>(std::max<unsigned>(hw, 1u), 64);
+    std::vector<SplitOut> outs(tasks);
+    std::vector<std::future<void>> futs;
+    for (size_t t = 0; t < tasks; ++t) {
+        const size_t lo = n * t / tasks, hi = n * (t + 1) / tasks;
+        futs.push_back(std::async(std::launch::async, [&, lo, hi, t]() {
+            for (size_t i = lo; i < hi; ++i) {
+                ClipPoly p; tri_poly(recs[i], p);
+                const PrimBounds box = refs_box[i];
+                split_rec(p, box, (uint32_t)i, thr, 0, &refs_box[i], -1, outs[t]);
+            }
+        }));
     }
+    for (auto& f : futs) f.get();
+    size_t extra = 0;
+    for (const SplitOut& o : outs) extra += o.box.size();
+    refs_box.reserve(n + extra); refs_tri.reserve(n + extra);
+    for (const SplitOut& o : outs) { refs_box.insert(refs_box.end(), o.box.begin(), o.box.end()); refs_tri.insert(refs_tri.end(), o.tri.begin(), o.tri.end()); }
 }
 
 // Appends a BLAS over the triangles of `node_ids` (TriMesh nodes sharing one isometry).
