@@ -34,9 +34,10 @@ def soak(name, sc, cam, configs, rounds):
                         bad += 1
                         print("DEVIATION", name, "config", ci, "round", r, sig, ref[key][1])
         if r == 2:
-            free0 = torch.cuda.mem_get_info()[0]
-    free1 = torch.cuda.mem_get_info()[0]
-    leak = (free0 - free1) if free0 is not None else 0
+            free0, res0 = torch.cuda.mem_get_info()[0], torch.cuda.memory_reserved()
+    free1, res1 = torch.cuda.mem_get_info()[0], torch.cuda.memory_reserved()
+    # device memory that went away and is not held by torch's caching allocator (the checks above allocate temporaries)
+    leak = ((free0 - free1) - (res1 - res0)) if free0 is not None else 0
     print("%s: %d frames in %.1f s, deviations %d, device memory drift %d bytes" % (name, n, time.time() - t0, bad, leak), flush=True)
     return bad + (1 if leak > (8 << 20) else 0)
 
