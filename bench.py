@@ -48,10 +48,18 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the nrays_amd product path has no CPU fallback")
+    # Plumbing test on a 1-GPU box (never the measured configuration): NRAYS_BENCH_ONE_DEVICE=1 puts every rank on
+    # cuda:0 and moves the tiles with gloo, so that the whole N > 1 code path of this file can be executed.
+    one_device = os.environ.get("NRAYS_BENCH_ONE_DEVICE") == "1"
+    if one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if one_device:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import __graft_entry__ as graft
     if rank == 0:
@@ -135,6 +143,12 @@ def main():
         dist.all_reduce(dt_t, op=dist.ReduceOp.MAX)
     dt = float(dt_t.item())
     tst = nr.get_stats(scene)  # HIP-event timings of the timed steps (render stream)
+
+    if one_device and world > 1 and rank == 0:  # plumbing test: the gathered, un-permuted frame equals a direct render
+        direct = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+        abi.check(lib.nrays_render_device(handle, C.byref(full), C.c_void_p(direct.data_ptr()), C.c_void_p(stream)))
+        torch.cuda.synchronize()
+        print("one-device plumbing test: gathered frame identical to a direct render: %s" % bool(torch.equal(direct, frame)), file=sys.stderr, flush=True)
 
     result = None
     if rank == 0:
