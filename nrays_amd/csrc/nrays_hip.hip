@@ -73,10 +73,16 @@ __device__ __forceinline__ void flush_counters(DeviceCounters* ctr, const Cnt& c
         if (stats) { nd += __shfl_down(nd, off); tr += __shfl_down(tr, off); pr += __shfl_down(pr, off); ht += __shfl_down(ht, off); tx += __shfl_down(tx, off); }
     }
 #ifdef NR_PHASE_TIMING
-    unsigned pn = c.cyc_node, pl = c.cyc_leaf; // accumulators only advance in active lanes: take the max over the wave
+    unsigned pn = c.cyc_node, pl = c.cyc_leaf, pt = c.cyc_tri; // accumulators only advance in active lanes: take the max over the wave
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { unsigned a = __shfl_down(pn, off), b = __shfl_down(pl, off); pn = a > pn ? a : pn; pl = b > pl ? b : pl; }
+    for (int off = 32; off > 0; off >>= 1) { unsigned a = __shfl_down(pn, off), b = __shfl_down(pl, off), t = __shfl_down(pt, off); pn = a > pn ? a : pn; pl = b > pl ? b : pl; pt = t > pt ? t : pt; }
+    unsigned i0 = c.wv_node, i1 = c.ln_node, i2 = c.wv_tri, i3 = c.ln_tri;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { i0 += __shfl_down(i0, off); i1 += __shfl_down(i1, off); i2 += __shfl_down(i2, off); i3 += __shfl_down(i3, off); }
     if (__lane_id() == 0) {
+        atomicAdd(&ctr->dbg[0], (unsigned long long)i0); atomicAdd(&ctr->dbg[1], (unsigned long long)i1);
+        atomicAdd(&ctr->dbg[2], (unsigned long long)i2); atomicAdd(&ctr->dbg[3], (unsigned long long)i3);
+        atomicAdd(&ctr->hit_records, (unsigned long long)pt);  // hit_records = triangle leaves (part of the leaf phases)
         atomicAdd(&ctr->node_tests, (unsigned long long)pn);   // tuning builds reuse the instrumented fields:
         atomicAdd(&ctr->tri_tests, (unsigned long long)pl);    // node_tests = cycles in node loops, tri_tests = leaf phases,
         atomicAdd(&ctr->prim_tests, (unsigned long long)c.cyc_other);  // prim_tests = whole-wave cycles
@@ -127,7 +133,7 @@ __global__ void __launch_bounds__(kBlock, waves_per_simd(FEAT)) k_primary(DScene
     st.sp = 0;
     Cnt cnt; cnt.node = cnt.tri = cnt.prim = cnt.hit = cnt.tex = cnt.shadow = cnt.refl = cnt.refr = cnt.max_depth = cnt.max_chain_nodes = 0;
 #ifdef NR_PHASE_TIMING
-    cnt.cyc_node = cnt.cyc_leaf = cnt.cyc_other = 0;
+    cnt.cyc_node = cnt.cyc_leaf = cnt.cyc_other = cnt.cyc_tri = 0; cnt.wv_node = cnt.ln_node = cnt.wv_tri = cnt.ln_tri = 0;
     unsigned long long twave = __builtin_readcyclecounter();
 #endif
 
@@ -203,7 +209,7 @@ __global__ void __launch_bounds__(kBlock, waves_per_simd(FEAT)) k_primary(DScene
                 // no ray of this wave tile gets past the root of the BVT: Scene::trace returns the background for
                 // all of them (scene.rs:157-161), without entering the trace loop
                 c = F3(S.background[0], S.background[1], S.background[2]);
-                if (STATS && active && S.closest_root >= 0) cnt.node += 4;
+                if (STATS && active && S.closest_root >= 0) cnt.node += root_children(S);
             } else {
                 c = trace_chain<STATS, FEAT>(S, st, active, ray, 0u, R.max_depth, qo, cnt, !PLAIN && R.use_rng != 0u);
             }
@@ -243,7 +249,7 @@ __global__ void __launch_bounds__(kBlock, NRAYS_WAVES_PER_SIMD) k_bounce(DScene 
     st.sp = 0;
     Cnt cnt; cnt.node = cnt.tri = cnt.prim = cnt.hit = cnt.tex = cnt.shadow = cnt.refl = cnt.refr = cnt.max_depth = cnt.max_chain_nodes = 0;
 #ifdef NR_PHASE_TIMING
-    cnt.cyc_node = cnt.cyc_leaf = cnt.cyc_other = 0;
+    cnt.cyc_node = cnt.cyc_leaf = cnt.cyc_other = cnt.cyc_tri = 0; cnt.wv_node = cnt.ln_node = cnt.wv_tri = cnt.ln_tri = 0;
 #endif
     uint32_t n = *count_in;
     if (n > capacity) n = capacity;
@@ -508,8 +514,11 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
     uint32_t grab = sc->host.any_mesh ? 1u : 0u; // 0 = workgroup lists through LDS; the specialised kernels fix their path at compile time
     if (const char* e = getenv("NRAYS_GRAB")) grab = (uint32_t)std::max(0, atoi(e)); // tiles per dequeue of the mesh kernels, A/B only (tools/kbench.py); pixels do not depend on it
     // persistent grid: exactly the workgroups that can be resident (one 4-wave workgroup per CU per wave/SIMD)
-    const uint32_t grid_primary = std::min<uint32_t>(std::min<uint32_t>(((ntiles + 7u) / 8u) * 8u, (uint32_t)kMaxGrid),
+    uint32_t grid_primary = std::min<uint32_t>(std::min<uint32_t>(((ntiles + 7u) / 8u) * 8u, (uint32_t)kMaxGrid),
                                                      (uint32_t)sc->num_cus * (uint32_t)waves_per_simd(instrumented ? kFeatAll : sc->features) * 256u / (uint32_t)kBlock);
+#ifdef NR_PHASE_TIMING
+    if (const char* e = getenv("NRAYS_GRID_WG_PER_CU")) grid_primary = std::min<uint32_t>(grid_primary, (uint32_t)sc->num_cus * (uint32_t)std::max(1, atoi(e))); // tuning builds: occupancy sensitivity
+#endif
 
     const int slot = (int)(sc->frames_recorded % NraysScene::kRing);
     // events: [pbegin .. pend] brackets the first primary launch; the frame spans [pbegin .. end], and
@@ -768,6 +777,18 @@ int nrays_get_stats(NraysScene* sc, NraysStats* out) {
     if (c.overflow) return fail(NRAYS_ERR_QUEUE_OVERFLOW, "continuation-ray queue overflow: image is incomplete");
     return NRAYS_OK;
 }
+
+#ifdef NR_PHASE_TIMING
+// Tuning builds only (tools/phase_timing.py): wave / lane iteration counts of the node loops and the triangle loops.
+int nrays_debug_counters(NraysScene* sc, unsigned long long out[4]) {
+    if (!sc || !sc->have_last) return NRAYS_ERR_BAD_ARG;
+    HIP_TRY(hipStreamSynchronize(sc->last_stream));
+    DeviceCounters c;
+    HIP_TRY(hipMemcpy(&c, sc->d_counters, sizeof c, hipMemcpyDeviceToHost));
+    for (int k = 0; k < 4; ++k) out[k] = c.dbg[k];
+    return NRAYS_OK;
+}
+#endif
 
 int nrays_get_primary_kernel_stats(NraysScene* sc, NraysStats* out) {
     if (!sc || !out) return fail(NRAYS_ERR_BAD_ARG, "null argument");

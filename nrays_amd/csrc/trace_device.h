@@ -83,10 +83,12 @@ constexpr unsigned long long kSaltPath = 2ULL, kSaltRefl = 0x100ULL, kSaltRefr =
 // Tuning builds only (tools/kbench.py --libs ...): wave-level s_memtime attribution of the cycles of a
 // wave to traversal phases; lane 0 accumulates, flush_counters sums over waves.
 #define NR_TIC(var) unsigned long long var = __builtin_readcyclecounter()
+#define NR_ITER(wv, ln) { cnt.ln++; if ((int)__lane_id() == __ffsll((long long)__ballot(1)) - 1) cnt.wv++; }
 #define NR_TOC(cntfield, var) { unsigned long long now_ = __builtin_readcyclecounter(); cnt.cntfield += (unsigned)(now_ - var); var = now_; }
 #else
 #define NR_TIC(var)
 #define NR_TOC(cntfield, var)
+#define NR_ITER(wv, ln)
 #endif
 struct Cnt {
     unsigned node, tri, prim, hit, tex;     // instrumented builds only
@@ -94,7 +96,8 @@ struct Cnt {
     unsigned max_depth;                     // deepest trace depth reached by this lane
     unsigned max_chain_nodes;               // instrumented: most AABB tests in one pixel's chain
 #ifdef NR_PHASE_TIMING
-    unsigned cyc_node, cyc_leaf, cyc_other; // per-wave cycles (valid in lane 0)
+    unsigned cyc_node, cyc_leaf, cyc_other, cyc_tri; // per-wave cycles (valid in lane 0); cyc_tri is part of cyc_leaf
+    unsigned wv_node, ln_node, wv_tri, ln_tri;       // iterations of the node loop / triangle loop: per wave (counted by the leading active lane) and per lane
 #endif
 };
 
@@ -597,6 +600,13 @@ NR_DEV bool primary_may_hit(const DScene& S, d3 o, d3 d) {
            (t2 >= 0.0f && ch.z != kEmptyChild) || (t3 >= 0.0f && ch.w != kEmptyChild);
 }
 
+// Number of boxes the root node holds (instrumented builds: the AABB tests primary_may_hit stands for).
+NR_DEV unsigned root_children(const DScene& S) {
+    if (S.closest_root < 0) return 0u;
+    int4 ch = ((const int4*)(S.nodes + S.closest_root))[6];
+    return (unsigned)(ch.x != kEmptyChild) + (unsigned)(ch.y != kEmptyChild) + (unsigned)(ch.z != kEmptyChild) + (unsigned)(ch.w != kEmptyChild);
+}
+
 // ncollide ray_aabb (AABB::toi_with_ray, solid = true; SURVEY B-3) as a predicate, in f64 and in the
 // reference's operation order.  The reference only casts a node / tests a triangle whose AABB this
 // test accepts (src/scene.rs:276 and the TriMesh BVT), so it is applied to every ACCEPTED hit; the
@@ -731,7 +741,9 @@ NR_DEV bool traverse(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, Hit&
             const float4* q = (const float4*)(S.nodes + cur);
             float4 mnx = q[0], mny = q[1], mnz = q[2], mxx = q[3], mxy = q[4], mxz = q[5];
             int4 ch = ((const int4*)q)[6];
-            if (STATS) cnt.node += 4;
+            NR_ITER(wv_node, ln_node);
+            // SURVEY 8d counts AABB tests: only the boxes that exist (an absent child slot is not a test)
+            if (STATS) cnt.node += (unsigned)(ch.x != kEmptyChild) + (unsigned)(ch.y != kEmptyChild) + (unsigned)(ch.z != kEmptyChild) + (unsigned)(ch.w != kEmptyChild);
             float t0, t1, t2, t3;
             box_entry4(mnx, mny, mnz, mxx, mxy, mxz, rf, btf, t0, t1, t2, t3);
             // misses (and absent children, whose inverted boxes always miss) sort last with key +inf
@@ -782,8 +794,7 @@ NR_DEV bool traverse(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, Hit&
         uint32_t lv = (uint32_t)~cur;
         uint32_t first = lv >> 3, bits = lv & 7u;
         if (kMesh && in_blas) { // triangle leaf
-            // the record of triangle k + 1 is fetched while triangle k is tested (a wave alone on its SIMD in the deep
-            // tail of a frame otherwise pays a full memory round trip per triangle)
+            NR_TIC(ttri);
             const float4* tq = (const float4*)(S.tris + first);
             float4 p0 = tq[0], p1 = tq[1], p2 = tq[2];
             const int32_t after_leaf = st.sp ? st.pop() : kEmptyChild; // popped now: the LDS latency hides behind the tests
@@ -792,6 +803,7 @@ NR_DEV bool traverse(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, Hit&
                 const float4 t0 = p0, t1 = p1, t2 = p2;
                 if (k < bits) { tq += 3; p0 = tq[0]; p1 = tq[1]; p2 = tq[2]; }
                 if (STATS) cnt.tri++;
+                NR_ITER(wv_tri, ln_tri);
                 double toi;
                 d3 va = D3(t0.x, t0.y, t0.z), vb = D3(t1.x, t1.y, t1.z), vc = D3(t2.x, t2.y, t2.z);
                 if (cast_triangle(va, vb, vc, co, cd, toi, nullptr, nullptr) &&
@@ -805,6 +817,7 @@ NR_DEV bool traverse(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, Hit&
                 }
             }
             cur = after_leaf;
+            NR_TOC(cyc_tri, ttri);
             continue;
         }
         if (kMesh && (!kAnalytic || (bits & kLeafMesh))) { // TLAS leaf: a BLAS

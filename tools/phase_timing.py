@@ -1,0 +1,46 @@
+#!/usr/bin/env python
+"""Where the wave cycles of the mesh kernels go (GPU box).  Needs a build with -DNR_PHASE_TIMING (tools/kres.py -o
+nrays_amd/lib/ab/lib_pt.so -DNR_PHASE_TIMING): the kernels then accumulate s_memtime differences per wave —
+node loops, leaf phases (of which triangle leaves), whole wave — into the counter fields read here.
+
+  NRAYS_HIP_LIB=nrays_amd/lib/ab/lib_pt.so python tools/phase_timing.py sponza hairball
+"""
+import ctypes as C
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import torch
+    import nrays_amd as nr
+    from nrays_amd import abi
+    from tests import scenes_util as su, standins
+    lib = abi.load_hip_lib()
+    for name in sys.argv[1:] or ["sponza", "hairball"]:
+        sc, cam = {"sponza": standins.sponza_scene, "hairball": standins.hairball_scene,
+                   "sponza8": lambda: standins.sponza_scene(n_lights=8), "balls": su.balls_scene}[name]()
+        p, _ = su.camera_params(cam, 1920, 1080)
+        out = torch.empty((1080, 1920, 3), dtype=torch.float32, device="cuda")
+        for _ in range(3):
+            abi.check(lib.nrays_render_device(sc.device_handle(), C.byref(p), C.c_void_p(out.data_ptr()), None))
+        st = nr.get_stats(sc)
+        tot = max(st.prim_tests, 1)
+        dbg = (C.c_ulonglong * 4)()
+        lib.nrays_debug_counters.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
+        abi.check(lib.nrays_debug_counters(sc.device_handle(), dbg))
+        print(json.dumps({"scene": name, "ms": round(st.kernel_ms_primary, 3), "wave_cycles": st.prim_tests,
+                          "node_loops": round(st.node_tests / tot, 3), "leaf_phases": round(st.tri_tests / tot, 3),
+                          "triangle_leaves": round(st.hit_records / tot, 3),
+                          "outside_traversal": round(1 - (st.node_tests + st.tri_tests) / tot, 3),
+                          "node_loop": {"wave_iterations": dbg[0], "lane_iterations": dbg[1], "simd_efficiency": round(dbg[1] / max(64 * dbg[0], 1), 3),
+                                        "cycles_per_wave_iteration": round(st.node_tests / max(dbg[0], 1))},
+                          "triangle_loop": {"wave_iterations": dbg[2], "lane_iterations": dbg[3], "simd_efficiency": round(dbg[3] / max(64 * dbg[2], 1), 3),
+                                            "cycles_per_wave_iteration": round(st.hit_records / max(dbg[2], 1))}}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
