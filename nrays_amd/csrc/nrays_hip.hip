@@ -198,7 +198,10 @@ __global__ void __launch_bounds__(kBlock, waves_per_simd(FEAT)) k_primary(DScene
         }
         bool active = i < R.width && rl < R.rows_local && j < R.height;
         uint32_t pix = rl * R.width + i;
+        // tot_c = tot_c + trace(ray) sample after sample (scene.rs:72-91): a later sample batch continues the running sum
+        // of the earlier ones, so the f32 summation order — and with it the frame — does not depend on the batching
         f3 tot = F3(0.0f, 0.0f, 0.0f);
+        if (!PLAIN && !R.first_batch && active) { const float* o = out + (size_t)pix * 3; tot = F3(o[0], o[1], o[2]); }
         const uint32_t s_begin = PLAIN ? 0u : R.sample_begin, s_end = PLAIN ? 1u : R.sample_end;
         for (uint32_t s = s_begin; s < s_end; ++s) {
             RayState ray;
@@ -218,8 +221,7 @@ __global__ void __launch_bounds__(kBlock, waves_per_simd(FEAT)) k_primary(DScene
         }
         if (active) {
             float* o = out + (size_t)pix * 3;
-            if (PLAIN || R.first_batch) { o[0] = tot.x; o[1] = tot.y; o[2] = tot.z; }
-            else { o[0] += tot.x; o[1] += tot.y; o[2] += tot.z; }
+            o[0] = tot.x; o[1] = tot.y; o[2] = tot.z;
         } else if (i < R.width && rl < R.rows_local && (PLAIN || R.first_batch)) { // padding rows of the last band
             float* o = out + (size_t)pix * 3;
             o[0] = 0.0f; o[1] = 0.0f; o[2] = 0.0f;
