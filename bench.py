@@ -2,15 +2,23 @@
 """bench.py — headline benchmark of the nrays trace loop on MI355X.
 
 Metric (BASELINE.json): Mrays/s (primary + shadow + reflection), 1920x1080, 4 bounces.
-A step = one scene::render of the workload: scenes/balls.scene at 1920x1080 with `refl 0.2 0.25`
-(exactly four reflection generations), 1 ray per pixel, inputs resident in HBM.
-A ray = one BVT query (primary, reflection, refraction or shadow; src/scene.rs:153,166).
+A step = one scene::render of the workload: scenes/balls.scene (loaded through the loader3d front-end) at
+1920x1080 with `refl 0.2 0.25` (exactly four reflection generations), 1 ray per pixel,
+inputs resident in HBM.  A ray = one BVT query (primary, reflection, refraction or shadow; src/scene.rs:153,166).
 
   python bench.py --gpus N --steps K --warmup W
-For N > 1 the driver launches it under torch.distributed.run, one rank per GPU: the frame is tiled in
-16-row bands dealt round-robin to the ranks, each rank renders its compact tile, one RCCL gather
-brings the tiles to rank 0, a HIP kernel un-permutes them (strong scaling: the frame is fixed).
-Rank 0 prints ONE JSON line.
+For N > 1 the driver launches it under torch.distributed.run, one rank per GPU: the frame is tiled in 16-row bands
+dealt round-robin to the ranks, each rank renders its compact tile, one RCCL gather brings the tiles to rank 0, a
+HIP kernel un-permutes them (strong scaling: the frame is fixed).  Rank 0 prints ONE JSON line.
+
+At N = 1 the line also carries
+  roofline       contract fields (achieved = algorithmic bytes / kernel time against the 8 TB/s HBM peak) PLUS what
+                 actually bounds the kernel: dram_frac (counter bytes / time / peak), valu_active_frac, fp64_issue_frac,
+                 l2_gbs, compulsory_bytes — from rocprofv3 --pmc passes run live by this script (traffic_source says
+                 whether the counters are live or replayed from profiles/);
+  cpu_baseline   the oracle (a port of the reference algorithm) on all host cores, scene built before the clock starts;
+  secondary      the crytek_sponza stand-in (BASELINE config 3, the north star's >= 100x target) with its own
+                 roofline and cpu_baseline blocks.
 """
 import argparse
 import ctypes as C
@@ -23,6 +31,167 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+NUM_SIMDS = 256 * 4    # same guide: 256 CUs x 4 SIMDs
+CLOCK_HZ = 2.4e9       # same guide: max clock (the effective clock under load is lower: fractions below are lower bounds)
+# SIMD cycles (s_memtime ticks) per wave64 instruction with the SIMD saturated, measured with tools/probe/valu_rate.hip on
+# MI355X (profiles/r02_valu_rate.json): v_fma/mul/add_f64 1.35 (f32: 1.05-1.27), v_rcp_f64 5.2.  A wave ALONE on its SIMD
+# issues one VALU instruction per ~5.4 cycles whatever its type: the kernels are bound by that per-wave issue latency at
+# 2-3 waves per SIMD, not by the f64 rate.
+CYCLES_PER_F64_WAVE_INSTR = 1.35
+CYCLES_PER_F64_TRANS_WAVE_INSTR = 5.2
+
+
+def load_workload(name):
+    """Returns (scene object with .descriptor / .device_handle(), camera dict, description)."""
+    if name == "balls":
+        from tools import gen_assets
+        from nrays_amd import scenefile
+        gen_assets.gen_globe()  # scenes/media/ is not shipped (as upstream, SURVEY F7): deterministic procedural globe.png
+        fs = scenefile.FileScene(os.path.join(ROOT, "scenes", "balls.scene"))
+        cam = fs.camera_dict()
+        return fs, cam, "scenes/balls.scene via the loader3d front-end, %dx%d, refl 0.2 0.25 (4 reflection bounces), 1 ray/pixel, procedural globe.png"
+    from tests import standins
+    sc, cam = standins.sponza_scene()
+    return sc, cam, "crytek_sponza STAND-IN (procedural, %d triangles, 276 nodes, alpha-mapped foliage; the real asset is not shipped upstream), " % standins.SPONZA_TRIS + "%dx%d, 1 light, 1 ray/pixel"
+
+
+def camera_params(cam, W, H):
+    import nrays_amd as nr
+    from nrays_amd import math3d
+    proj = math3d.inverse_projection(cam["eye"], cam["at"], cam["fovy"], W, H)
+    return nr.make_params((W, H), 1, 0.0, cam["eye"], proj)
+
+
+def roofline_block(pk, tst, W, owned_rows, scene_bytes, pmc, pmc_source):
+    """SURVEY 8d roofline of the dominant kernel (k_primary) + the bounds that actually hold."""
+    bytes_primary = pk.algorithmic_bytes(W, owned_rows)
+    t = tst.kernel_ms_primary * 1e-3
+    achieved = bytes_primary / t / 1e9 if t > 0 else 0.0
+    fb = 12 * W * owned_rows
+    r = {"bound": "hbm", "kernel": "k_primary", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "traffic_source": None,
+         "algorithmic_bytes_per_launch": int(bytes_primary), "kernel_ms": round(tst.kernel_ms_primary, 5),
+         "frame_gpu_ms": round(tst.kernel_ms_total, 5), "launches_timed": int(tst.frames_timed),
+         "compulsory_bytes": int(scene_bytes + fb),
+         "units_per_launch": {"rays": int(pk.total_rays()), "node_tests": int(pk.node_tests), "tri_tests": int(pk.tri_tests),
+                              "prim_tests": int(pk.prim_tests), "hit_records": int(pk.hit_records), "tex_samples": int(pk.tex_samples)},
+         "note": "frac = algorithmic record bytes (SURVEY 8d formula, AABB tests counted per existing child box) / kernel time / "
+                 "HBM peak: a rate of useful bytes, NOT a DRAM utilisation — the scene is cache-resident, see dram_frac; the "
+                 "kernel is bound by VALU issue x SIMD divergence (valu_active_frac, DESIGN.md 5)"}
+    if pmc and t > 0:
+        r["traffic_source"] = pmc_source
+        if pmc.get("hbm_bytes_per_launch") is not None:
+            r["traffic"] = float(pmc["hbm_bytes_per_launch"])
+            r["dram_frac"] = round(pmc["hbm_bytes_per_launch"] / t / 1e9 / HBM_PEAK_GBS, 5)
+        simd_cycles = NUM_SIMDS * t * CLOCK_HZ
+        if pmc.get("SQ_ACTIVE_INST_VALU") is not None:  # quad-cycles summed over waves
+            r["valu_active_frac"] = round(4.0 * pmc["SQ_ACTIVE_INST_VALU"] / simd_cycles, 4)
+        f64 = [pmc.get(k) for k in ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_TRANS_F64")]
+        if all(v is not None for v in f64):
+            r["f64_wave_instructions"] = int(sum(f64))
+            r["fp64_issue_frac"] = round((sum(f64[:3]) * CYCLES_PER_F64_WAVE_INSTR + f64[3] * CYCLES_PER_F64_TRANS_WAVE_INSTR) / simd_cycles, 4)
+        if pmc.get("SQ_INSTS_VALU") is not None:
+            r["valu_wave_instructions"] = int(pmc["SQ_INSTS_VALU"])
+        if pmc.get("TCC_HIT_sum") is not None and pmc.get("TCC_MISS_sum") is not None:
+            req = pmc["TCC_HIT_sum"] + pmc["TCC_MISS_sum"]
+            r["l2_hit_rate"] = round(pmc["TCC_HIT_sum"] / max(req, 1.0), 4)
+            r["l2_gbs"] = round(req * 128.0 / t / 1e9, 1)  # 128-byte L2 requests (MI355X_MICROARCH.md §HBM)
+        if pmc.get("errors"):
+            r["pmc_errors"] = pmc["errors"][:2]
+    return r
+
+
+def pmc_for(workload, W, H, live):
+    """Counters of the primary kernel on `workload`: live rocprofv3 passes, else the committed collection."""
+    from tools import pmc_collect
+    if live:
+        try:
+            res = pmc_collect.collect(workload, pmc_collect.TRAFFIC_PASSES, steps=3, width=W, height=H, timeout=240)
+            if res.get("hbm_bytes_per_launch") is not None or res.get("SQ_ACTIVE_INST_VALU") is not None:
+                return res, "live: rocprofv3 --pmc (2 passes, tools/pmc_collect.py TRAFFIC_PASSES) on tools/kbench.py --child %s in this run" % workload
+        except Exception as e:  # the bench line must not depend on the profiler
+            print("live PMC collection failed: %r" % (e,), file=sys.stderr)
+    path = os.path.join(ROOT, "profiles", "r02_pmc_%s.json" % workload)
+    if os.path.exists(path) and (W, H) == (1920, 1080):
+        try:
+            return json.load(open(path)), "replayed from profiles/r02_pmc_%s.json (python tools/pmc_collect.py %s ...; not measured in this run)" % (workload, workload)
+        except Exception:
+            pass
+    return None, None
+
+
+def cpu_baseline(scene, params, budget_s):
+    """The CPU leg: the oracle (a port of the reference algorithm: f64, best-first two-level BVT, recursive trace) on
+    all host cores with the reference's static pixel partition (scene.rs:49-66).  The BVTs are built before the clock
+    starts (Scene::new is outside scene::render, loader3d.rs:57-93), the threads are created once and each renders its
+    range `reps` times; the sample is sized to at least ~1.5 s of wall time (10-30 CPU-seconds and more on a many-core
+    host), at most `budget_s`."""
+    import oracle  # the checker, used here only as the timed CPU baseline
+    cores = os.cpu_count() or 1
+    sec, st = oracle.render_timed(scene.descriptor, params, cores, 1)
+    reps = int(max(1, min(4096, 1.5 / max(sec, 1e-4), budget_s / max(sec, 1e-4))))
+    if reps > 1:
+        sec, st = oracle.render_timed(scene.descriptor, params, cores, reps)
+    rays = max(st.total_rays(), 1)
+    sample = "%d x full %dx%d frame, %d rays, %.2f s wall on %d persistent threads (%.0f CPU-s), BVT build excluded" % (
+        reps, params.width, params.height, rays, sec, cores, sec * cores)
+    # SURVEY 8d: the same rays through the reference-equivalent tree (median split, one primitive per leaf, best-first
+    # search), reported beside the shipped BVH's counts in roofline.units_per_launch
+    ref_counts = {"aabb_tests_per_ray": round(st.node_tests / rays, 2), "tri_tests_per_ray": round(st.tri_tests / rays, 2),
+                  "prim_tests_per_ray": round(st.prim_tests / rays, 3)}
+    return {"value": round(rays / sec / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port", "sample": sample,
+            "reference_tree_counts": ref_counts}
+
+
+def reference_toolchain_probe():
+    """if a Rust toolchain AND the upstream assets were on the box, real loader3d would be timed too."""
+    import shutil
+    cargo = shutil.which("cargo")
+    media = os.path.join(ROOT, "scenes", "media", "crytek-sponza", "sponza.obj")
+    return {"cargo": cargo or "absent", "upstream_assets": "present" if os.path.exists(media) else "absent (scenes/media is not shipped upstream)",
+            "rust_reference_timed": False}
+
+
+def single_gpu_measure(name, W, H, steps, warmup, args):
+    """One workload on the current device: instrumented frame (counts), timed loop, roofline, CPU baseline."""
+    import torch
+    import nrays_amd as nr
+    from nrays_amd import abi
+    lib = abi.load_hip_lib()
+    scene, cam, desc = load_workload(name)
+    p = camera_params(cam, W, H)
+    handle = scene.device_handle()
+    out = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def render(instrumented=False):
+        fn = lib.nrays_render_device_instrumented if instrumented else lib.nrays_render_device
+        abi.check(fn(handle, C.byref(p), C.c_void_p(out.data_ptr()), C.c_void_p(stream)))
+
+    render(True)
+    st = nr.get_stats(scene)
+    pk = abi.NraysStats()
+    abi.check(lib.nrays_get_primary_kernel_stats(handle, C.byref(pk)))
+    for _ in range(warmup):
+        render()
+    nr.get_stats(scene)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        render()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tst = nr.get_stats(scene)
+    pmc, src = (None, None) if args.no_pmc else pmc_for(name, W, H, live=not args.replay_pmc)
+    res = {"workload": desc % (W, H), "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 5),
+           "value": round(st.total_rays() * steps / dt / 1e6, 3), "unit": "Mrays/s",
+           "rays_per_frame": {"total": int(st.total_rays()), "primary": int(st.rays_primary), "reflection": int(st.rays_reflection),
+                              "refraction": int(st.rays_refraction), "shadow": int(st.rays_shadow)},
+           "roofline": roofline_block(pk, tst, W, H, lib.nrays_scene_device_bytes(handle), pmc, src)}
+    if not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(scene, p, args.cpu_seconds)
+        res["gpu_over_cpu"] = round(res["value"] / max(res["cpu_baseline"]["value"], 1e-9), 1)
+    return res
 
 
 def main():
@@ -34,10 +203,12 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--scene", default="balls", choices=["balls", "sponza"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU-baseline leg")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the sponza stand-in block")
+    ap.add_argument("--no-pmc", action="store_true", help="no hardware counters at all (traffic: null)")
+    ap.add_argument("--replay-pmc", action="store_true", help="take the counters from profiles/ instead of running rocprofv3")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall-time cap of each CPU-baseline leg")
     args = ap.parse_args()
 
-    import numpy as np
     import torch
     import torch.distributed as dist
 
@@ -64,126 +235,16 @@ def main():
     import __graft_entry__ as graft
     if rank == 0:
         graft.build()
+        from tools import gen_assets
+        gen_assets.gen_globe()  # before the other ranks load scenes/balls.scene
     if world > 1:
         dist.barrier()
-    import nrays_amd as nr
-    from nrays_amd import abi, tiling
-    from tests import scenes_util as su
 
-    lib = abi.load_hip_lib()
-    W, H = args.width, args.height
-    if args.scene == "balls":
-        scene, cam = su.balls_scene()
-        workload = "scenes/balls.scene %dx%d, refl 0.2 0.25 (4 reflection bounces), 1 ray/pixel, procedural globe texture" % (W, H)
+    if world == 1:
+        result = run_single(args)
     else:
-        from tests import standins
-        scene, cam = standins.sponza_scene()
-        workload = "crytek_sponza stand-in (procedural, %d tris) %dx%d, 1 light" % (standins.SPONZA_TRIS, W, H)
-    full, _ = su.camera_params(cam, W, H)
-    band = tiling.DEFAULT_BAND_ROWS
-    p = tiling.tile_params(full, rank, world, band)
-    rows = lib.nrays_tile_rows(C.byref(p))
-    tiles = [torch.zeros((rows, W, 3), dtype=torch.float32, device="cuda") for _ in range(2)]
-    tile = tiles[0]
-    handle = scene.device_handle()
-    stream = torch.cuda.current_stream().cuda_stream
-
-    def render(instrumented=False, into=None):
-        fn = lib.nrays_render_device_instrumented if instrumented else lib.nrays_render_device
-        abi.check(fn(handle, C.byref(p), C.c_void_p((tile if into is None else into).data_ptr()), C.c_void_p(stream)))
-
-    frame = torch.empty((H, W, 3), dtype=torch.float32, device="cuda") if rank == 0 else None
-
-    # N > 1: render k+1 overlaps the RCCL gather of frame k (nrays_amd.tiling.FramePipeline); every frame is
-    # gathered and un-permuted on rank 0 before the timed region ends (flush()).
-    pipe = tiling.FramePipeline(rank, world, tiles, lambda t: render(into=t),
-                                lambda g, idx: tiling.untile_device(g, W, H, band, world, out=frame)) if world > 1 else None
-
-    def step():
-        if pipe is None:
-            render()
-        else:
-            pipe.step()
-
-    # ---- untimed: instrumented frame -> ray counts and algorithmic bytes of the dominant kernel ----
-    render(instrumented=True)
-    st = nr.get_stats(scene)
-    pk = abi.NraysStats()
-    abi.check(lib.nrays_get_primary_kernel_stats(handle, C.byref(pk)))
-    rays_local = st.total_rays()
-    rays_t = torch.tensor([rays_local, st.rays_primary, st.rays_reflection, st.rays_refraction, st.rays_shadow],
-                          dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(rays_t)
-    rays_total = float(rays_t[0].item())
-    owned = len(tiling.owned_rows(H, band, rank, world)) if world > 1 else H
-    bytes_primary = pk.algorithmic_bytes(W, owned)
-
-    for _ in range(args.warmup):
-        step()
-    if pipe is not None:
-        pipe.flush()
-    nr.get_stats(scene)  # drains the event ring so that the averages below cover the timed steps only
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    if pipe is not None:
-        pipe.flush()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    dt_t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(dt_t, op=dist.ReduceOp.MAX)
-    dt = float(dt_t.item())
-    tst = nr.get_stats(scene)  # HIP-event timings of the timed steps (render stream)
-
-    if one_device and world > 1 and rank == 0:  # plumbing test: the gathered, un-permuted frame equals a direct render
-        direct = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
-        abi.check(lib.nrays_render_device(handle, C.byref(full), C.c_void_p(direct.data_ptr()), C.c_void_p(stream)))
-        torch.cuda.synchronize()
-        print("one-device plumbing test: gathered frame identical to a direct render: %s" % bool(torch.equal(direct, frame)), file=sys.stderr, flush=True)
-
-    result = None
+        result = run_tiled(args, rank, world, one_device)
     if rank == 0:
-        ms_per_step = dt / args.steps * 1e3
-        value = rays_total * args.steps / dt / 1e6
-        t_primary = tst.kernel_ms_primary * 1e-3
-        achieved = bytes_primary / t_primary / 1e9 if t_primary > 0 else 0.0
-        traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_k_primary.json")  # collected for the balls workload at 1920x1080
-        if os.path.exists(pmc_path) and args.scene == "balls" and (W, H) == (1920, 1080) and world == 1:
-            try:
-                traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        result = {
-            "metric": "Mrays/s (primary+shadow+reflection), 1920x1080, 4 bounces",
-            "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": workload, "resolution": [W, H], "ray_per_pixel": 1,
-                       "parallelism": "framebuffer bands x%d + RCCL gather" % world if world > 1 else "1 GPU",
-                       "rays_per_frame": {"total": int(rays_total), "primary": int(rays_t[1].item()),
-                                          "reflection": int(rays_t[2].item()), "refraction": int(rays_t[3].item()),
-                                          "shadow": int(rays_t[4].item())}},
-            "roofline": {"bound": "hbm", "kernel": "k_primary", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": int(bytes_primary),
-                         "kernel_ms": round(tst.kernel_ms_primary, 5), "frame_gpu_ms": round(tst.kernel_ms_total, 5),
-                         "launches_timed": int(tst.frames_timed),
-                         "units_per_launch": {"rays": int(pk.total_rays()), "node_tests": int(pk.node_tests),
-                                              "tri_tests": int(pk.tri_tests), "prim_tests": int(pk.prim_tests),
-                                              "hit_records": int(pk.hit_records), "tex_samples": int(pk.tex_samples)}},
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(scene, full, args.cpu_seconds)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
@@ -191,47 +252,104 @@ def main():
     return result
 
 
-def cpu_baseline(scene, params, budget_s):
-    """The CPU leg: the oracle (a port of the reference algorithm: f64, best-first two-level BVT,
-    recursive trace) on all host cores with the reference's static pixel partition (scene.rs:49-66),
-    on a bounded sample of the same workload: the full frame if it fits the time budget, else the
-    top rows of it (ray counts scale the rate, which is what is reported)."""
-    import oracle  # the checker, used here only as the timed CPU baseline
-    from nrays_amd import abi
-    cores = os.cpu_count() or 1
-    probe = abi.NraysRenderParams()
-    C.memmove(C.byref(probe), C.byref(params), C.sizeof(probe))
-    # probe: every 16th band of 16 rows (a 1/16 sample of the frame spread over its height)
-    probe.band_rows, probe.band_owner, probe.band_owners = 16, 7, 16
+def run_single(args):
+    W, H = args.width, args.height
+    m = single_gpu_measure(args.scene, W, H, args.steps, args.warmup, args)
+    result = {
+        "metric": "Mrays/s (primary+shadow+reflection), 1920x1080, 4 bounces",
+        "value": m["value"], "unit": "Mrays/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": m["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": m["workload"], "resolution": [W, H], "ray_per_pixel": 1, "parallelism": "1 GPU",
+                   "rays_per_frame": m["rays_per_frame"]},
+        "roofline": m["roofline"],
+    }
+    if "cpu_baseline" in m:
+        result["cpu_baseline"] = m["cpu_baseline"]
+    if args.scene == "balls" and not args.no_secondary:
+        # BASELINE config 3 / the north star's ">= 100x CPU on crytek_sponza at 1 GPU": same process, same run
+        s = single_gpu_measure("sponza", W, H, max(10, min(args.steps, 60)), max(3, min(args.warmup, 10)), args)
+        result["secondary"] = {"sponza_standin": s}
+    result["reference_toolchain"] = reference_toolchain_probe()
+    return result
+
+
+def run_tiled(args, rank, world, one_device):
+    """N > 1: one rank per GPU, band tiling, RCCL gather to rank 0, k_untile."""
+    import torch
+    import torch.distributed as dist
+    import nrays_amd as nr
+    from nrays_amd import abi, tiling
+    lib = abi.load_hip_lib()
+    W, H = args.width, args.height
+    scene, cam, desc = load_workload(args.scene)
+    full = camera_params(cam, W, H)
+    band = tiling.DEFAULT_BAND_ROWS
+    p = tiling.tile_params(full, rank, world, band)
+    rows = lib.nrays_tile_rows(C.byref(p))
+    tiles = [torch.zeros((rows, W, 3), dtype=torch.float32, device="cuda") for _ in range(2)]
+    handle = scene.device_handle()
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def render(instrumented=False, into=None):
+        fn = lib.nrays_render_device_instrumented if instrumented else lib.nrays_render_device
+        abi.check(fn(handle, C.byref(p), C.c_void_p((tiles[0] if into is None else into).data_ptr()), C.c_void_p(stream)))
+
+    frame = torch.empty((H, W, 3), dtype=torch.float32, device="cuda") if rank == 0 else None
+    # render k+1 overlaps the RCCL gather of frame k (nrays_amd.tiling.FramePipeline); every frame is gathered and
+    # un-permuted on rank 0 before the timed region ends (flush()).
+    pipe = tiling.FramePipeline(rank, world, tiles, lambda t: render(into=t),
+                                lambda g, idx: tiling.untile_device(g, W, H, band, world, out=frame))
+
+    render(instrumented=True)
+    st = nr.get_stats(scene)
+    pk = abi.NraysStats()
+    abi.check(lib.nrays_get_primary_kernel_stats(handle, C.byref(pk)))
+    rays_t = torch.tensor([st.total_rays(), st.rays_primary, st.rays_reflection, st.rays_refraction, st.rays_shadow],
+                          dtype=torch.float64, device="cuda")
+    dist.all_reduce(rays_t)
+    rays_total = float(rays_t[0].item())
+    owned = len(tiling.owned_rows(H, band, rank, world))
+
+    for _ in range(args.warmup):
+        pipe.step()
+    pipe.flush()
+    nr.get_stats(scene)  # drains the event ring so that the averages below cover the timed steps only
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
-    _, st = oracle.render(scene.descriptor, probe, cores)
-    t_probe = max(time.perf_counter() - t0, 1e-6)
-    rate = st.total_rays() / t_probe
-    est_full = 16.0 * t_probe
-    if est_full <= budget_s:
-        # whole frames, repeated until the sample is worth ~10-30 s of CPU time (cores x wall), at most `budget_s` of wall
-        t0 = time.perf_counter()
-        oracle.render(scene.descriptor, params, cores)
-        t_frame = max(time.perf_counter() - t0, 1e-6)  # the probe above pays the thread start-up: time one real frame
-        reps = int(max(1, min(256, 20.0 / (t_frame * cores), budget_s / t_frame)))
-        rays = 0
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            _, st = oracle.render(scene.descriptor, params, cores)
-            rays += st.total_rays()
-        dt = time.perf_counter() - t0
-        rate = rays / dt
-        sample = "%d x full %dx%d frame, %d rays, %.2f s wall on %d threads (%.0f CPU-s)" % (
-            reps, params.width, params.height, rays, dt, cores, dt * cores)
-    else:
-        sample = "1/16 of the frame (every 16th 16-row band), %d rays, %.2f s" % (st.total_rays(), t_probe)
-    rays = max(st.total_rays(), 1)
-    # SURVEY 8d: the same rays through the reference-equivalent tree (median split, one primitive per leaf, best-first
-    # search), reported beside the shipped BVH's counts in roofline.units_per_launch
-    ref_counts = {"aabb_tests_per_ray": round(st.node_tests / rays, 2), "tri_tests_per_ray": round(st.tri_tests / rays, 2),
-                  "prim_tests_per_ray": round(st.prim_tests / rays, 3)}
-    return {"value": round(rate / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port", "sample": sample,
-            "reference_tree_counts": ref_counts}
+    for _ in range(args.steps):
+        pipe.step()
+    pipe.flush()
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    dt_t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    dist.all_reduce(dt_t, op=dist.ReduceOp.MAX)
+    dt = float(dt_t.item())
+    tst = nr.get_stats(scene)  # HIP-event timings of the timed steps (render stream)
+
+    if one_device and rank == 0:  # plumbing test: the gathered, un-permuted frame equals a direct render
+        direct = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+        abi.check(lib.nrays_render_device(handle, C.byref(full), C.c_void_p(direct.data_ptr()), C.c_void_p(stream)))
+        torch.cuda.synchronize()
+        print("one-device plumbing test: gathered frame identical to a direct render: %s" % bool(torch.equal(direct, frame)), file=sys.stderr, flush=True)
+    if rank != 0:
+        return None
+    return {
+        "metric": "Mrays/s (primary+shadow+reflection), 1920x1080, 4 bounces",
+        "value": round(rays_total * args.steps / dt / 1e6, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": desc % (W, H), "resolution": [W, H], "ray_per_pixel": 1,
+                   "parallelism": "framebuffer bands x%d + RCCL gather" % world,
+                   "rays_per_frame": {"total": int(rays_total), "primary": int(rays_t[1].item()), "reflection": int(rays_t[2].item()),
+                                      "refraction": int(rays_t[3].item()), "shadow": int(rays_t[4].item())}},
+        # rank 0's tile kernel; no counters at N > 1 (the profiler leg runs at N = 1 only)
+        "roofline": roofline_block(pk, tst, W, owned, lib.nrays_scene_device_bytes(handle), None, None),
+    }
 
 
 if __name__ == "__main__":

@@ -223,6 +223,10 @@ int nrays_get_stats(NraysScene* scene, NraysStats* out_stats);
  * behind bench.py's roofline figure. */
 int nrays_get_primary_kernel_stats(NraysScene* scene, NraysStats* out_stats);
 
+/* Device bytes of the flattened scene (BVH nodes, triangle records, instance / shading records, textures): what
+ * a frame must read at least once — the compulsory part of bench.py's roofline block. */
+uint64_t nrays_scene_device_bytes(const NraysScene* scene);
+
 void nrays_scene_destroy(NraysScene* scene);
 
 const char* nrays_last_error(void);

@@ -98,6 +98,7 @@ HIP_SYMBOLS = {
     "nrays_untile_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),
     "nrays_get_stats": (C.c_int, [C.c_void_p, C.POINTER(NraysStats)]),
     "nrays_get_primary_kernel_stats": (C.c_int, [C.c_void_p, C.POINTER(NraysStats)]),
+    "nrays_scene_device_bytes": (C.c_uint64, [C.c_void_p]),
     "nrays_scene_destroy": (None, [C.c_void_p]),
     "nrays_last_error": (C.c_char_p, []),
     "nrays_abi_version": (C.c_uint32, []),

@@ -357,6 +357,7 @@ struct NraysScene {
     HostScene host;          // kept for counts only; bulk arrays are released after upload
     DScene d;
     std::vector<void*> allocs;
+    uint64_t scene_bytes = 0; // device bytes of the uploaded scene arrays (BVH nodes, triangles, records, textures)
     // per-scene transient state, grown on demand
     QueueMem queue[2];
     uint32_t queue_capacity = 0;
@@ -401,6 +402,7 @@ static int upload(NraysScene* sc, const std::vector<T>& v, const T** out) {
     void* p = nullptr;
     HIP_TRY(hipMalloc(&p, v.size() * sizeof(T)));
     sc->allocs.push_back(p);
+    sc->scene_bytes += v.size() * sizeof(T);
     HIP_TRY(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
     *out = (const T*)p;
     return NRAYS_OK;
@@ -631,6 +633,7 @@ extern "C" {
 uint32_t nrays_abi_version(void) { return NRAYS_ABI_VERSION; }
 const char* nrays_last_error(void) { return g_last_error.c_str(); }
 uint32_t nrays_tile_rows(const NraysRenderParams* params) { return params ? tile_rows(params) : 0; }
+uint64_t nrays_scene_device_bytes(const NraysScene* scene) { return scene ? scene->scene_bytes : 0; }
 
 int nrays_scene_create(const NraysSceneDesc* desc, NraysScene** out_scene) {
     if (!desc || !out_scene) return fail(NRAYS_ERR_BAD_ARG, "null argument");
@@ -664,6 +667,7 @@ int nrays_scene_create(const NraysSceneDesc* desc, NraysScene** out_scene) {
         void* p = nullptr;
         if (hipMalloc(&p, t.bytes.size()) != hipSuccess) return bail(fail(NRAYS_ERR_OOM, "texture allocation failed"));
         sc->allocs.push_back(p);
+        sc->scene_bytes += t.bytes.size();
         if (hipMemcpy(p, t.bytes.data(), t.bytes.size(), hipMemcpyHostToDevice) != hipSuccess) return bail(fail(NRAYS_ERR_HIP, "texture upload failed"));
         TextureRec r = t.rec; r.texels = p; trecs.push_back(r);
         std::vector<uint8_t>().swap(t.bytes);

@@ -29,6 +29,10 @@ def lib():
         l.nrays_oracle_render.restype = C.c_int
         l.nrays_oracle_render.argtypes = [C.POINTER(abi.NraysSceneDesc), C.POINTER(abi.NraysRenderParams),
                                           C.POINTER(C.c_float), C.c_int, C.POINTER(abi.NraysStats)]
+        l.nrays_oracle_render_timed.restype = C.c_int
+        l.nrays_oracle_render_timed.argtypes = [C.POINTER(abi.NraysSceneDesc), C.POINTER(abi.NraysRenderParams),
+                                                C.POINTER(C.c_float), C.c_int, C.c_int, C.POINTER(abi.NraysStats),
+                                                C.POINTER(C.c_double)]
         l.nrays_oracle_cast_batch.restype = C.c_int
         l.nrays_oracle_cast_batch.argtypes = [C.POINTER(abi.NraysSceneDesc), C.c_uint32, C.POINTER(C.c_double),
                                               C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double),
@@ -61,6 +65,24 @@ def render(descriptor, params, num_threads=1):
     if rc != 0:
         raise RuntimeError("oracle render failed: %d %s" % (rc, l.nrays_oracle_last_error()))
     return out, st
+
+
+def render_timed(descriptor, params, num_threads, reps):
+    """bench.py's cpu_baseline leg: `reps` frames on persistent threads with the scene built before the clock starts.
+    Returns (seconds of the threaded region, NraysStats summed over the `reps` frames)."""
+    l = lib()
+    rows = params.height
+    if params.band_rows and params.band_owners > 1:
+        nb = (params.height + params.band_rows - 1) // params.band_rows
+        rows = ((nb + params.band_owners - 1) // params.band_owners) * params.band_rows
+    out = np.zeros((rows, params.width, 3), dtype=np.float32)
+    st = abi.NraysStats()
+    sec = C.c_double(0.0)
+    rc = l.nrays_oracle_render_timed(descriptor.pointer(), C.byref(params), out.ctypes.data_as(C.POINTER(C.c_float)),
+                                     int(num_threads), int(reps), C.byref(st), C.byref(sec))
+    if rc != 0:
+        raise RuntimeError("oracle render failed: %d %s" % (rc, l.nrays_oracle_last_error()))
+    return sec.value, st
 
 
 def cast(descriptor, origins, dirs, bruteforce=False):

@@ -23,7 +23,8 @@
  *   rotations are applied as 3x3 matrices built from the axis-angle (nalgebra applies the unit
  *        quaternion directly; identical for angle = 0, 1e-16 apart otherwise).
  *
- * Build: gcc -O2 -std=c11 -ffp-contract=off (Rust never fuses a*b+c; neither does this file).
+ * Build: gcc -O3 -std=c11 -ffp-contract=off (Rust never fuses a*b+c; neither does this file).  No -march=native:
+ * the library is built in one container and timed on another host (bench.py's cpu_baseline).
  */
 #define _GNU_SOURCE
 #include <float.h>
@@ -33,6 +34,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "../include/nrays_abi.h"
 
@@ -1058,11 +1060,15 @@ static c3 render_pixel(const OScene* sc, const NraysRenderParams* p, uint32_t i,
 typedef struct {
     const OScene* sc; const NraysRenderParams* p; float* out;
     size_t low, up; Counters cnt;
+    int reps;                  /* the thread renders its range this many times (1 for a plain render) */
+    pthread_barrier_t* start;  /* timed runs only */
 } Job;
 
 static void* render_job(void* arg) {
     Job* jb = (Job*)arg;
     const NraysRenderParams* p = jb->p;
+    if (jb->start) pthread_barrier_wait(jb->start); /* timed runs: all threads leave the gate together */
+    for (int rep = 0; rep < jb->reps; ++rep)
     for (size_t ipt = jb->low; ipt < jb->up; ++ipt) {
         uint32_t j = (uint32_t)(ipt / p->width), i = (uint32_t)(ipt - (size_t)j * p->width);
         if (!row_owned(p, j)) continue;
@@ -1078,8 +1084,26 @@ const char* nrays_oracle_last_error(void) { return g_err; }
 
 /* The oracle entry point.  Same descriptors and output layout as nrays_render.  `num_threads`
  * follows scene.rs:49-66: contiguous static ranges of parts = npixels/num_threads + 1 pixels. */
+static int oracle_render_impl(const NraysSceneDesc* desc, const NraysRenderParams* params, float* out_rgb,
+                              int num_threads, NraysStats* stats, int reps, double* seconds);
+
 int nrays_oracle_render(const NraysSceneDesc* desc, const NraysRenderParams* params, float* out_rgb,
                         int num_threads, NraysStats* stats) {
+    return oracle_render_impl(desc, params, out_rgb, num_threads, stats, 1, NULL);
+}
+
+/* The CPU-baseline form (bench.py): the scene (BVTs) is built BEFORE the clock starts, as Scene::new is outside
+ * scene::render in the reference (loader3d.rs:57-93); the threads are created once, wait at a barrier, and each renders
+ * its static pixel range (scene.rs:49-66) `reps` times; `*seconds` is the wall time from the barrier to the last join.
+ * `stats` holds the counts of all `reps` frames. */
+int nrays_oracle_render_timed(const NraysSceneDesc* desc, const NraysRenderParams* params, float* out_rgb,
+                              int num_threads, int reps, NraysStats* stats, double* seconds) {
+    if (reps < 1 || !seconds) { snprintf(g_err, sizeof g_err, "bad timing arguments"); return NRAYS_ERR_BAD_ARG; }
+    return oracle_render_impl(desc, params, out_rgb, num_threads, stats, reps, seconds);
+}
+
+static int oracle_render_impl(const NraysSceneDesc* desc, const NraysRenderParams* params, float* out_rgb,
+                              int num_threads, NraysStats* stats, int reps, double* seconds) {
     if (!desc || !params || !out_rgb) { snprintf(g_err, sizeof g_err, "null argument"); return NRAYS_ERR_BAD_ARG; }
     if (params->ray_per_pixel == 0 || params->width == 0 || params->height == 0) {
         snprintf(g_err, sizeof g_err, "ray_per_pixel, width and height must be > 0"); return NRAYS_ERR_BAD_ARG;
@@ -1093,12 +1117,23 @@ int nrays_oracle_render(const NraysSceneDesc* desc, const NraysRenderParams* par
     pthread_t* th = (pthread_t*)calloc((size_t)num_threads, sizeof(pthread_t));
     size_t parts = npixels / (size_t)num_threads + 1;
     for (int t = 0; t < num_threads; ++t) {
-        jobs[t].sc = &sc; jobs[t].p = params; jobs[t].out = out_rgb;
+        jobs[t].sc = &sc; jobs[t].p = params; jobs[t].out = out_rgb; jobs[t].reps = reps; jobs[t].start = NULL;
         jobs[t].low = parts * (size_t)t;
         jobs[t].up = parts * (size_t)(t + 1) < npixels ? parts * (size_t)(t + 1) : npixels;
         if (jobs[t].low > npixels) jobs[t].low = npixels;
     }
-    if (num_threads == 1) render_job(&jobs[0]);
+    if (seconds) { /* timed: threads + the caller meet at a barrier, the clock runs from there to the last join */
+        pthread_barrier_t gate;
+        struct timespec t0, t1;
+        pthread_barrier_init(&gate, NULL, (unsigned)num_threads + 1u);
+        for (int t = 0; t < num_threads; ++t) { jobs[t].start = &gate; pthread_create(&th[t], NULL, render_job, &jobs[t]); }
+        pthread_barrier_wait(&gate);
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        for (int t = 0; t < num_threads; ++t) pthread_join(th[t], NULL);
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        pthread_barrier_destroy(&gate);
+        *seconds = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+    } else if (num_threads == 1) render_job(&jobs[0]);
     else {
         for (int t = 0; t < num_threads; ++t) pthread_create(&th[t], NULL, render_job, &jobs[t]);
         for (int t = 0; t < num_threads; ++t) pthread_join(th[t], NULL);
