@@ -8,8 +8,9 @@ inputs resident in HBM.  A ray = one BVT query (primary, reflection, refraction 
 
   python bench.py --gpus N --steps K --warmup W
 For N > 1 the driver launches it under torch.distributed.run, one rank per GPU: the frame is tiled in 16-row bands
-dealt round-robin to the ranks, each rank renders its compact tile, one RCCL gather brings the tiles to rank 0, a
-HIP kernel un-permutes them (strong scaling: the frame is fixed).  Rank 0 prints ONE JSON line.
+dealt round-robin to the ranks, each rank renders its compact tile, grouped RCCL send / receive brings the tiles to
+GPU 0, a HIP kernel un-permutes them — all inside the library (nrays_render_multi_device, one C call per frame; strong
+scaling: the frame is fixed).  Rank 0 prints ONE JSON line.  (`--gpus N` without a launcher: one process drives N owners.)
 
 At N = 1 the line also carries
   roofline       contract fields (achieved = algorithmic bytes / kernel time against the 8 TB/s HBM peak) PLUS what
@@ -219,18 +220,10 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the nrays_amd product path has no CPU fallback")
-    # Plumbing test on a 1-GPU box (never the measured configuration): NRAYS_BENCH_ONE_DEVICE=1 puts every rank on
-    # cuda:0 and moves the tiles with gloo, so that the whole N > 1 code path of this file can be executed.
-    one_device = os.environ.get("NRAYS_BENCH_ONE_DEVICE") == "1"
-    if one_device:
-        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if one_device:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import __graft_entry__ as graft
     if rank == 0:
@@ -240,10 +233,10 @@ def main():
     if world > 1:
         dist.barrier()
 
-    if world == 1:
+    if world == 1 and args.gpus == 1:
         result = run_single(args)
     else:
-        result = run_tiled(args, rank, world, one_device)
+        result = run_tiled(args, rank, world, args.gpus)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
@@ -274,8 +267,13 @@ def run_single(args):
     return result
 
 
-def run_tiled(args, rank, world, one_device):
-    """N > 1: one rank per GPU, band tiling, RCCL gather to rank 0, k_untile."""
+def run_tiled(args, rank, world, owners):
+    """N > 1 through the library's own multi-GPU path (nrays_render_multi_device, multi_gpu.cpp): band
+    tiling, grouped RCCL send / receive to owner 0, k_untile — one C call per frame and rank, no Python in the step.
+      world > 1   one process per GPU (torch.distributed.run): rank r drives owner r; torch.distributed only ships the
+                  128-byte RCCL unique id, the barriers and the final reductions;
+      world == 1  `--gpus N` without a launcher: ONE process drives N owners on the visible devices (owner o on device
+                  o % device_count: on a 1-GPU box a plumbing run of the N-owner path, never a measurement)."""
     import torch
     import torch.distributed as dist
     import nrays_amd as nr
@@ -284,72 +282,87 @@ def run_tiled(args, rank, world, one_device):
     W, H = args.width, args.height
     scene, cam, desc = load_workload(args.scene)
     full = camera_params(cam, W, H)
-    band = tiling.DEFAULT_BAND_ROWS
-    p = tiling.tile_params(full, rank, world, band)
-    rows = lib.nrays_tile_rows(C.byref(p))
-    tiles = [torch.zeros((rows, W, 3), dtype=torch.float32, device="cuda") for _ in range(2)]
-    handle = scene.device_handle()
-    stream = torch.cuda.current_stream().cuda_stream
-
-    def render(instrumented=False, into=None):
-        fn = lib.nrays_render_device_instrumented if instrumented else lib.nrays_render_device
-        abi.check(fn(handle, C.byref(p), C.c_void_p((tiles[0] if into is None else into).data_ptr()), C.c_void_p(stream)))
-
+    if world > 1:
+        uid = torch.zeros(abi.UNIQUE_ID_BYTES, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            uid.copy_(torch.tensor(list(tiling.unique_id()), dtype=torch.uint8))
+        dist.broadcast(uid, 0)
+        comm = tiling.ranked_comm(bytes(uid.cpu().tolist()), world, rank)
+        mode = "one process per GPU, framebuffer bands x%d + RCCL send/recv to GPU 0 (nrays_render_multi_device)" % owners
+    else:
+        ndev = torch.cuda.device_count()
+        comm = tiling.local_comm(owners, [o % ndev for o in range(owners)])
+        mode = "ONE process drives %d owners on %d device(s), framebuffer bands + %s (nrays_render_multi_device)" % (
+            owners, ndev, "RCCL send/recv to GPU 0" if ndev > 1 else "device-to-device copies: plumbing run, not a measurement")
+    ss = tiling.SceneSet(scene.descriptor, comm)
     frame = torch.empty((H, W, 3), dtype=torch.float32, device="cuda") if rank == 0 else None
-    # render k+1 overlaps the RCCL gather of frame k (nrays_amd.tiling.FramePipeline); every frame is gathered and
-    # un-permuted on rank 0 before the timed region ends (flush()).
-    pipe = tiling.FramePipeline(rank, world, tiles, lambda t: render(into=t),
-                                lambda g, idx: tiling.untile_device(g, W, H, band, world, out=frame))
+    fptr = frame.data_ptr() if frame is not None else 0
 
-    render(instrumented=True)
-    st = nr.get_stats(scene)
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # untimed: this rank's first owner renders its tile instrumented -> units of the dominant kernel; one plain frame -> ray classes
+    owner0, h0 = ss.local_scenes()[0]
+    band = tiling.DEFAULT_BAND_ROWS
+    tp = tiling.tile_params(full, owner0, owners, band)
+    rows = lib.nrays_tile_rows(C.byref(tp))
+    scratch = torch.empty((rows, W, 3), dtype=torch.float32, device="cuda")
+    abi.check(lib.nrays_render_device_instrumented(h0, C.byref(tp), C.c_void_p(scratch.data_ptr()), None))
     pk = abi.NraysStats()
-    abi.check(lib.nrays_get_primary_kernel_stats(handle, C.byref(pk)))
+    abi.check(lib.nrays_get_primary_kernel_stats(h0, C.byref(pk)))
+    ss.render_device(full, fptr)
+    ss.sync()
+    st = ss.stats()
     rays_t = torch.tensor([st.total_rays(), st.rays_primary, st.rays_reflection, st.rays_refraction, st.rays_shadow],
                           dtype=torch.float64, device="cuda")
-    dist.all_reduce(rays_t)
+    if world > 1:
+        dist.all_reduce(rays_t)
     rays_total = float(rays_t[0].item())
-    owned = len(tiling.owned_rows(H, band, rank, world))
 
     for _ in range(args.warmup):
-        pipe.step()
-    pipe.flush()
-    nr.get_stats(scene)  # drains the event ring so that the averages below cover the timed steps only
-    torch.cuda.synchronize()
-    dist.barrier()
-    torch.cuda.synchronize()
+        ss.render_device(full, fptr)
+    ss.sync()
+    ss.stats()  # drains the event rings so that the averages below cover the timed steps only
+    barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        pipe.step()
-    pipe.flush()
-    torch.cuda.synchronize()
-    dist.barrier()
-    torch.cuda.synchronize()
+        ss.render_device(full, fptr)
+    ss.sync()  # every frame is rendered, exchanged and un-permuted on owner 0 before the clock stops
+    barrier()
     dt = time.perf_counter() - t0
-    dt_t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    dist.all_reduce(dt_t, op=dist.ReduceOp.MAX)
-    dt = float(dt_t.item())
-    tst = nr.get_stats(scene)  # HIP-event timings of the timed steps (render stream)
+    if world > 1:
+        dt_t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(dt_t, op=dist.ReduceOp.MAX)
+        dt = float(dt_t.item())
+    tst = ss.stats()  # HIP-event timings of this rank's first owner over the timed steps
 
-    if one_device and rank == 0:  # plumbing test: the gathered, un-permuted frame equals a direct render
+    check = None
+    if rank == 0:  # the gathered, un-permuted frame equals a direct single-GPU render of the whole frame (untimed)
         direct = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
-        abi.check(lib.nrays_render_device(handle, C.byref(full), C.c_void_p(direct.data_ptr()), C.c_void_p(stream)))
+        abi.check(lib.nrays_render_device(scene.device_handle(), C.byref(full), C.c_void_p(direct.data_ptr()), None))
         torch.cuda.synchronize()
-        print("one-device plumbing test: gathered frame identical to a direct render: %s" % bool(torch.equal(direct, frame)), file=sys.stderr, flush=True)
-    if rank != 0:
-        return None
-    return {
-        "metric": "Mrays/s (primary+shadow+reflection), 1920x1080, 4 bounces",
-        "value": round(rays_total * args.steps / dt / 1e6, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(dt / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "f64", "data": "synthetic",
-        "config": {"workload": desc % (W, H), "resolution": [W, H], "ray_per_pixel": 1,
-                   "parallelism": "framebuffer bands x%d + RCCL gather" % world,
-                   "rays_per_frame": {"total": int(rays_total), "primary": int(rays_t[1].item()), "reflection": int(rays_t[2].item()),
-                                      "refraction": int(rays_t[3].item()), "shadow": int(rays_t[4].item())}},
-        # rank 0's tile kernel; no counters at N > 1 (the profiler leg runs at N = 1 only)
-        "roofline": roofline_block(pk, tst, W, owned, lib.nrays_scene_device_bytes(handle), None, None),
-    }
+        check = bool(torch.equal(direct, frame))
+    result = None
+    if rank == 0:
+        owned = len(tiling.owned_rows(H, band, owner0, owners))
+        result = {
+            "metric": "Mrays/s (primary+shadow+reflection), 1920x1080, 4 bounces",
+            "value": round(rays_total * args.steps / dt / 1e6, 3), "unit": "Mrays/s", "n_gpus": owners, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": desc % (W, H), "resolution": [W, H], "ray_per_pixel": 1, "parallelism": mode,
+                       "tiled_frame_identical_to_single_gpu_render": check,
+                       "rays_per_frame": {"total": int(rays_total), "primary": int(rays_t[1].item()), "reflection": int(rays_t[2].item()),
+                                          "refraction": int(rays_t[3].item()), "shadow": int(rays_t[4].item())}},
+            # owner 0's tile kernel; no counters at N > 1 (the profiler leg runs at N = 1 only)
+            "roofline": roofline_block(pk, tst, W, owned, lib.nrays_scene_device_bytes(h0), None, None),
+        }
+    ss.close()
+    lib.nrays_comm_destroy(comm)
+    return result
 
 
 if __name__ == "__main__":

@@ -38,7 +38,8 @@ typedef enum NraysStatus {
     NRAYS_ERR_OOM = -3,            /* host or device allocation failed */
     NRAYS_ERR_UNSUPPORTED = -4,    /* e.g. mesh vertices that are not f32-exact */
     NRAYS_ERR_NO_DEVICE = -5,      /* no gfx950 device visible to the process */
-    NRAYS_ERR_QUEUE_OVERFLOW = -6  /* continuation-ray queue capacity exceeded */
+    NRAYS_ERR_QUEUE_OVERFLOW = -6, /* continuation-ray queue capacity exceeded */
+    NRAYS_ERR_RCCL = -7            /* an RCCL call failed (multi-GPU entry points) */
 } NraysStatus;
 
 /* Shapes the loader can construct (examples/loader3d.rs:593-695). */
@@ -228,6 +229,48 @@ int nrays_get_primary_kernel_stats(NraysScene* scene, NraysStats* out_stats);
 uint64_t nrays_scene_device_bytes(const NraysScene* scene);
 
 void nrays_scene_destroy(NraysScene* scene);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Multi-GPU: the framebuffer tiled over the GPUs of one node (replaces the thread partition of src/scene.rs:49-66).
+ * The scene is replicated on every GPU, bands of 16 rows are dealt round-robin to the owners, every owner renders its
+ * compact tile, ONE exchange (grouped RCCL send / receive over xGMI, every peer straight to owner 0) brings the tiles
+ * to owner 0, which un-permutes them.  The frame is bit-identical for any number of owners.
+ *
+ *   one process, all GPUs (what a Rust caller of scene::render uses):
+ *       nrays_comm_create_local(n, NULL, &comm); nrays_scene_set_create(&desc, comm, &set);
+ *       nrays_render_multi(set, &params, frame);            // = scene::render on n GPUs
+ *   one process per GPU (torch.distributed.run, MPI, ...): rank 0 calls nrays_comm_unique_id, ships the 128 bytes to
+ *       the other ranks by its own means, every rank calls nrays_comm_create(id, n, rank, &comm) on ITS device, then
+ *       nrays_scene_set_create / nrays_render_multi[_device] collectively; rank 0 receives the frame.
+ * The band fields of NraysRenderParams are ignored (the set owns the partition). */
+#define NRAYS_UNIQUE_ID_BYTES 128
+typedef struct NraysComm NraysComm;         /* opaque */
+typedef struct NraysSceneSet NraysSceneSet; /* opaque */
+
+int nrays_comm_unique_id(uint8_t out_id[NRAYS_UNIQUE_ID_BYTES]);
+int nrays_comm_create(const uint8_t id[NRAYS_UNIQUE_ID_BYTES], uint32_t num_ranks, uint32_t rank, NraysComm** out_comm);
+/* `devices`: HIP device index of every owner, or NULL for owner o on device o % device_count.  Owners may share a
+ * device (their tiles then move by device-to-device copies): a 1-GPU box can run the N-owner path. */
+int nrays_comm_create_local(uint32_t num_owners, const int32_t* devices, NraysComm** out_comm);
+uint32_t nrays_comm_owners(const NraysComm* comm);
+void nrays_comm_destroy(NraysComm* comm); /* after every scene set that uses it */
+
+int nrays_scene_set_create(const NraysSceneDesc* desc, NraysComm* comm, NraysSceneSet** out_set);
+void nrays_scene_set_destroy(NraysSceneSet* set);
+/* The per-GPU scene handles behind a set (owned by the set): for instrumented renders and per-GPU statistics of one
+ * owner's tile (nrays_render_device_instrumented / nrays_get_stats with that owner's band parameters). */
+uint32_t nrays_scene_set_num_local(const NraysSceneSet* set);
+NraysScene* nrays_scene_set_local_scene(NraysSceneSet* set, uint32_t k, uint32_t* out_owner);
+
+/* scene::render on the group; `out_rgb` is HOST memory (height*width*3 floats), filled on the process that drives
+ * owner 0 (NULL elsewhere).  Blocking. */
+int nrays_render_multi(NraysSceneSet* set, const NraysRenderParams* params, float* out_rgb);
+/* Same with DEVICE memory on owner 0's GPU and no final synchronisation: consecutive calls form a depth-1 pipeline
+ * (the tile render of frame k + 1 overlaps the exchange of frame k).  nrays_multi_sync waits for everything enqueued. */
+int nrays_render_multi_device(NraysSceneSet* set, const NraysRenderParams* params, float* out_rgb_device);
+int nrays_multi_sync(NraysSceneSet* set);
+/* Counters of the last frame summed over the owners this process drives. */
+int nrays_multi_get_stats(NraysSceneSet* set, NraysStats* out_stats);
 
 const char* nrays_last_error(void);
 

@@ -16,6 +16,8 @@ ERR_OOM = -3
 ERR_UNSUPPORTED = -4
 ERR_NO_DEVICE = -5
 ERR_QUEUE_OVERFLOW = -6
+ERR_RCCL = -7
+UNIQUE_ID_BYTES = 128
 
 # NraysShapeKind (examples/loader3d.rs:593-695)
 SHAPE_BALL, SHAPE_CUBOID, SHAPE_CYLINDER, SHAPE_CAPSULE, SHAPE_CONE, SHAPE_PLANE, SHAPE_TRIMESH = range(7)
@@ -100,6 +102,19 @@ HIP_SYMBOLS = {
     "nrays_get_primary_kernel_stats": (C.c_int, [C.c_void_p, C.POINTER(NraysStats)]),
     "nrays_scene_device_bytes": (C.c_uint64, [C.c_void_p]),
     "nrays_scene_destroy": (None, [C.c_void_p]),
+    "nrays_comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
+    "nrays_comm_create": (C.c_int, [C.POINTER(C.c_uint8), C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
+    "nrays_comm_create_local": (C.c_int, [C.c_uint32, C.POINTER(C.c_int32), C.POINTER(C.c_void_p)]),
+    "nrays_comm_owners": (C.c_uint32, [C.c_void_p]),
+    "nrays_comm_destroy": (None, [C.c_void_p]),
+    "nrays_scene_set_create": (C.c_int, [C.POINTER(NraysSceneDesc), C.c_void_p, C.POINTER(C.c_void_p)]),
+    "nrays_scene_set_destroy": (None, [C.c_void_p]),
+    "nrays_scene_set_num_local": (C.c_uint32, [C.c_void_p]),
+    "nrays_scene_set_local_scene": (C.c_void_p, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]),
+    "nrays_render_multi": (C.c_int, [C.c_void_p, C.POINTER(NraysRenderParams), C.POINTER(C.c_float)]),
+    "nrays_render_multi_device": (C.c_int, [C.c_void_p, C.POINTER(NraysRenderParams), C.c_void_p]),
+    "nrays_multi_sync": (C.c_int, [C.c_void_p]),
+    "nrays_multi_get_stats": (C.c_int, [C.c_void_p, C.POINTER(NraysStats)]),
     "nrays_last_error": (C.c_char_p, []),
     "nrays_abi_version": (C.c_uint32, []),
 }

@@ -334,6 +334,7 @@ __global__ void k_untile(const float* __restrict__ gathered, float* __restrict__
 // =============================================================================================
 static thread_local std::string g_last_error;
 static int fail(int status, const std::string& msg) { g_last_error = msg; return status; }
+int set_last_error(int status, const std::string& msg) { return fail(status, msg); } // for the library's other translation units (multi_gpu.cpp)
 
 #define HIP_TRY(expr)                                                                                     \
     do {                                                                                                  \

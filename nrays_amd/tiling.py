@@ -120,3 +120,81 @@ class FramePipeline:
 
     def flush(self):
         self._finish()
+
+
+class SceneSet:
+    """The library's own multi-GPU path (include/nrays_abi.h, nrays_amd/csrc/multi_gpu.cpp): a scene replicated on the
+    GPUs of a communicator, one call per frame.  `comm` comes from local_comm() (one process drives every owner) or
+    ranked_comm() (one process per GPU)."""
+
+    def __init__(self, descriptor, comm):
+        lib = abi.load_hip_lib()
+        self._lib, self._comm = lib, comm
+        h = C.c_void_p()
+        abi.check(lib.nrays_scene_set_create(descriptor.pointer(), comm, C.byref(h)))
+        self._h = h
+        self.owners = lib.nrays_comm_owners(comm)
+
+    def render(self, params, out=None):
+        """scene::render on the group; returns the (H, W, 3) float32 frame on the process that drives owner 0."""
+        import numpy as np
+        if out is None:
+            out = np.empty((params.height, params.width, 3), dtype=np.float32)
+        abi.check(self._lib.nrays_render_multi(self._h, C.byref(params), out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    def render_device(self, params, out_ptr):
+        abi.check(self._lib.nrays_render_multi_device(self._h, C.byref(params), C.c_void_p(out_ptr)))
+
+    def sync(self):
+        abi.check(self._lib.nrays_multi_sync(self._h))
+
+    def stats(self):
+        st = abi.NraysStats()
+        abi.check(self._lib.nrays_multi_get_stats(self._h, C.byref(st)))
+        return st
+
+    def local_scenes(self):
+        """[(owner index, NraysScene* handle)] of the owners this process drives (handles stay owned by the set)."""
+        out = []
+        for k in range(self._lib.nrays_scene_set_num_local(self._h)):
+            o = C.c_uint32()
+            out.append((o.value, C.c_void_p(self._lib.nrays_scene_set_local_scene(self._h, k, C.byref(o)))))
+            out[-1] = (o.value, out[-1][1])
+        return out
+
+    def close(self):
+        if self._h is not None:
+            self._lib.nrays_scene_set_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def local_comm(owners, devices=None):
+    """One process, `owners` band owners on `devices` (None: owner o on device o % device_count)."""
+    lib = abi.load_hip_lib()
+    c = C.c_void_p()
+    dv = (C.c_int32 * owners)(*devices) if devices is not None else None
+    abi.check(lib.nrays_comm_create_local(owners, dv, C.byref(c)))
+    return c
+
+
+def unique_id():
+    lib = abi.load_hip_lib()
+    buf = (C.c_uint8 * abi.UNIQUE_ID_BYTES)()
+    abi.check(lib.nrays_comm_unique_id(buf))
+    return bytes(buf)
+
+
+def ranked_comm(id_bytes, world, rank):
+    """One process per GPU: rank `rank` of `world`, on the calling thread's current device."""
+    lib = abi.load_hip_lib()
+    c = C.c_void_p()
+    buf = (C.c_uint8 * abi.UNIQUE_ID_BYTES)(*id_bytes)
+    abi.check(lib.nrays_comm_create(buf, world, rank, C.byref(c)))
+    return c

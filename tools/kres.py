@@ -29,7 +29,7 @@ def main():
             extra.append(a)
     os.makedirs(os.path.dirname(out), exist_ok=True)
     srcs = [os.path.join(g.CSRC, s) for s in g.HIP_SOURCES]
-    cmd = ["/opt/rocm/bin/hipcc"] + g.HIP_FLAGS + extra + ["-Rpass-analysis=kernel-resource-usage", "-o", out] + srcs
+    cmd = ["/opt/rocm/bin/hipcc"] + g.HIP_FLAGS + extra + ["-Rpass-analysis=kernel-resource-usage", "-o", out] + srcs + g.HIP_LINK
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         print(r.stdout[-4000:])
