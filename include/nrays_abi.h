@@ -186,6 +186,12 @@ typedef struct NraysStats {
     uint32_t reserved;
 } NraysStats;
 
+/* Threading contract of a scene handle: the library is re-entrant on DISTINCT handles (any threads, any streams).
+ * ONE handle must not be used by two threads at the same time (its calls must be serialised by the caller); its
+ * renders execute in call order — a render enqueued on another stream than its predecessor is ordered behind it by
+ * the library — because the handle owns per-frame device state (counters, continuation queues, raygen tables, tile
+ * costs).  The environment switches NRAYS_MAX_PRIMARY / NRAYS_GRAB / NRAYS_LPT (tests and A/B runs) are read once,
+ * by nrays_scene_create. */
 typedef struct NraysScene NraysScene; /* opaque */
 
 /* Builds the device-resident scene on the CURRENT HIP device of the calling thread: flattens the

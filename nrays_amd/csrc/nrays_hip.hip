@@ -388,7 +388,12 @@ struct NraysScene {
     uint64_t frames_recorded = 0, frames_reported = 0;
     DeviceCounters* d_counters_primary = nullptr; // snapshot taken right after the primary kernel
     hipStream_t last_stream = nullptr;
+    hipEvent_t last_done = nullptr; // last event recorded by the previous render (one of the ring's events)
     bool have_last = false;
+    // A/B and test switches, read ONCE when the handle is created (never in the frame path)
+    uint64_t max_primary_per_launch = 32ull << 20; // NRAYS_MAX_PRIMARY: sample batching threshold (tests force several launches)
+    int grab_override = -1;                         // NRAYS_GRAB
+    bool lpt_enabled = true;                        // NRAYS_LPT=0 restores image order
     NraysStats last;
     uint64_t last_primary = 0, last_primary_first_batch = 0;
     bool last_instrumented = false;
@@ -489,8 +494,7 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
     if (npix_local >= (1ull << 31)) return fail(NRAYS_ERR_UNSUPPORTED, "tile too large");
 
     // sample batching keeps the number of primary rays (and hence continuation rays) per launch bounded
-    uint64_t kMaxPrimaryPerLaunch = 32ull << 20;
-    if (const char* e = getenv("NRAYS_MAX_PRIMARY")) kMaxPrimaryPerLaunch = (uint64_t)std::max(1ll, atoll(e)); // tests: force sample batching
+    const uint64_t kMaxPrimaryPerLaunch = sc->max_primary_per_launch;
     uint32_t batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(p->ray_per_pixel, kMaxPrimaryPerLaunch / std::max<uint64_t>(1, npix_local)));
 
     // Continuation rays stay in registers (trace_chain); the HBM queue is only needed when one hit can
@@ -517,7 +521,7 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
     const uint32_t tiles_x = (p->width + kTile - 1) / kTile, tiles_y = (rows + kTile - 1) / kTile;
     const uint32_t ntiles = tiles_x * tiles_y;
     uint32_t grab = sc->host.any_mesh ? 1u : 0u; // 0 = workgroup lists through LDS; the specialised kernels fix their path at compile time
-    if (const char* e = getenv("NRAYS_GRAB")) grab = (uint32_t)std::max(0, atoi(e)); // tiles per dequeue of the mesh kernels, A/B only (tools/kbench.py); pixels do not depend on it
+    if (sc->grab_override >= 0) grab = (uint32_t)sc->grab_override; // tiles per dequeue of the mesh kernels, A/B only (NRAYS_GRAB); pixels do not depend on it
     // persistent grid: exactly the workgroups that can be resident (one 4-wave workgroup per CU per wave/SIMD)
     uint32_t grid_primary = std::min<uint32_t>(std::min<uint32_t>(((ntiles + 7u) / 8u) * 8u, (uint32_t)kMaxGrid),
                                                      (uint32_t)sc->num_cus * (uint32_t)waves_per_simd(instrumented ? kFeatAll : sc->features) * 256u / (uint32_t)kBlock);
@@ -525,10 +529,13 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
     if (const char* e = getenv("NRAYS_GRID_WG_PER_CU")) grid_primary = std::min<uint32_t>(grid_primary, (uint32_t)sc->num_cus * (uint32_t)std::max(1, atoi(e))); // tuning builds: occupancy sensitivity
 #endif
 
+    // All per-handle state (double-buffered counters, queues, raygen tables, tile costs) assumes that the renders of one
+    // handle execute one after the other: a render on a different stream than its predecessor is ordered behind it.
+    if (sc->have_last && sc->last_stream != stream && sc->last_done) HIP_TRY(hipStreamWaitEvent(stream, sc->last_done, 0));
     const int slot = (int)(sc->frames_recorded % NraysScene::kRing);
     // events: [pbegin .. pend] brackets the first primary launch; the frame spans [pbegin .. end], and
     // `end` is only recorded separately when something follows the primary kernel
-    const bool single_launch = !queued && p->ray_per_pixel <= batch && p->ray_per_pixel == 1;
+    const bool single_launch = !instrumented && !queued && p->ray_per_pixel <= batch && p->ray_per_pixel == 1;
     sc->d_counters = sc->d_counters_set[sc->frame_index & 1];
     DeviceCounters* next_ctr = sc->d_counters_set[(sc->frame_index + 1) & 1];
     sc->frame_index++;
@@ -553,7 +560,7 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
     R.tile_cost = nullptr; R.tile_order = nullptr;
     sc->has_prepass[slot] = false;
     bool lpt = grab >= 1u;
-    if (const char* e = getenv("NRAYS_LPT")) lpt = lpt && atoi(e) != 0; // A/B switch (tools/kbench.py)
+    lpt = lpt && sc->lpt_enabled; // A/B switch (NRAYS_LPT=0)
     if (lpt) {
         const uint32_t nwt = ntiles * 4u;
         if (nwt > sc->tile_slots) {
@@ -615,6 +622,7 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
     }
     if (!single_launch) HIP_TRY(hipEventRecord(sc->ev_end[slot], stream));
     sc->single_launch[slot] = single_launch;
+    sc->last_done = single_launch ? sc->ev_pend[slot] : sc->ev_end[slot];
     sc->frames_recorded++;
     sc->last_stream = stream; sc->have_last = true;
     // owned rows only (padding rows of the last band carry no rays)
@@ -693,6 +701,9 @@ int nrays_scene_create(const NraysSceneDesc* desc, NraysScene** out_scene) {
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, sc->device) == hipSuccess && cus > 0) sc->num_cus = cus;
     }
     sc->features = h.features ? h.features : kFeatAll;
+    if (const char* e = getenv("NRAYS_MAX_PRIMARY")) sc->max_primary_per_launch = (uint64_t)std::max(1ll, atoll(e));
+    if (const char* e = getenv("NRAYS_GRAB")) sc->grab_override = std::max(0, atoi(e));
+    if (const char* e = getenv("NRAYS_LPT")) sc->lpt_enabled = atoi(e) != 0;
     // release bulk host copies
     std::vector<BvhNode>().swap(h.nodes); std::vector<TriRec>().swap(h.tris); std::vector<TriUv>().swap(h.triuvs);
 

@@ -1,8 +1,9 @@
 // loader3d.cpp — the reference's CLI (examples/loader3d.rs:34-101) over the C ABI:
-//   loader3d <scene_file> [--width W --height H] [--spp N --window X] [--max-depth D] [--standins] [--ppm] [--cpu-threads N]
+//   loader3d <scene_file> [--width W --height H] [--spp N --window X] [--max-depth D] [--gpus N] [--standins] [--ppm]
 // Loads the scene, creates the device scene once (nrays_scene_create), renders every camera with
-// nrays_render and writes the PNG named by the camera's `output`.  libnrays_hip.so is dlopen'ed so the
-// front-end itself builds without ROCm.
+// nrays_render — or, with --gpus N, with nrays_render_multi on N band owners (one per visible GPU, round-robin) —
+// and writes the PNG named by the camera's `output`.  libnrays_hip.so is dlopen'ed so the front-end itself builds
+// without ROCm.
 #include <dlfcn.h>
 
 #include <chrono>
@@ -17,15 +18,15 @@
 using namespace nrays_host;
 
 int main(int argc, char** argv) {
-    if (argc < 2) { std::fprintf(stderr, "Usage: %s scene_file [--width W --height H --spp N --window X --max-depth D --standins --ppm]\n", argv[0]); return 2; }
+    if (argc < 2) { std::fprintf(stderr, "Usage: %s scene_file [--width W --height H --spp N --window X --max-depth D --gpus N --standins --ppm]\n", argv[0]); return 2; }
     std::string path = argv[1];
-    long ow = 0, oh = 0, ospp = 0, maxd = 0; double owin = -1.0; bool standins = false, ppm = false;
+    long ow = 0, oh = 0, ospp = 0, maxd = 0, gpus = 1; double owin = -1.0; bool standins = false, ppm = false;
     for (int i = 2; i < argc; ++i) {
         std::string a = argv[i];
         auto val = [&]() -> const char* { if (i + 1 >= argc) { std::fprintf(stderr, "missing value for %s\n", a.c_str()); std::exit(2); } return argv[++i]; };
         if (a == "--width") ow = std::atol(val()); else if (a == "--height") oh = std::atol(val());
         else if (a == "--spp") ospp = std::atol(val()); else if (a == "--window") owin = std::atof(val());
-        else if (a == "--max-depth") maxd = std::atol(val()); else if (a == "--standins") standins = true; else if (a == "--ppm") ppm = true;
+        else if (a == "--max-depth") maxd = std::atol(val()); else if (a == "--gpus") gpus = std::atol(val()); else if (a == "--standins") standins = true; else if (a == "--ppm") ppm = true;
         else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
     }
     try {
@@ -45,9 +46,20 @@ int main(int argc, char** argv) {
         auto destroy = (void (*)(NraysScene*))dlsym(h, "nrays_scene_destroy");
         auto last_error = (const char* (*)())dlsym(h, "nrays_last_error");
         auto get_stats = (int (*)(NraysScene*, NraysStats*))dlsym(h, "nrays_get_stats");
-        if (!create || !render || !destroy || !last_error || !get_stats) { std::fprintf(stderr, "libnrays_hip.so lacks an ABI symbol\n"); return 1; }
-        NraysScene* scene = nullptr;
-        if (create(&sc->desc, &scene) != NRAYS_OK) { std::fprintf(stderr, "nrays_scene_create: %s\n", last_error()); return 1; }
+        auto comm_create_local = (int (*)(uint32_t, const int32_t*, NraysComm**))dlsym(h, "nrays_comm_create_local");
+        auto comm_destroy = (void (*)(NraysComm*))dlsym(h, "nrays_comm_destroy");
+        auto set_create = (int (*)(const NraysSceneDesc*, NraysComm*, NraysSceneSet**))dlsym(h, "nrays_scene_set_create");
+        auto set_destroy = (void (*)(NraysSceneSet*))dlsym(h, "nrays_scene_set_destroy");
+        auto render_multi = (int (*)(NraysSceneSet*, const NraysRenderParams*, float*))dlsym(h, "nrays_render_multi");
+        auto multi_stats = (int (*)(NraysSceneSet*, NraysStats*))dlsym(h, "nrays_multi_get_stats");
+        if (!create || !render || !destroy || !last_error || !get_stats || !comm_create_local || !comm_destroy || !set_create || !set_destroy || !render_multi || !multi_stats) {
+            std::fprintf(stderr, "libnrays_hip.so lacks an ABI symbol\n"); return 1;
+        }
+        NraysScene* scene = nullptr; NraysComm* comm = nullptr; NraysSceneSet* set = nullptr;
+        if (gpus > 1) { // the frame tiled over `gpus` band owners (scene replicated, RCCL exchange, see include/nrays_abi.h)
+            if (comm_create_local((uint32_t)gpus, nullptr, &comm) != NRAYS_OK) { std::fprintf(stderr, "nrays_comm_create_local: %s\n", last_error()); return 1; }
+            if (set_create(&sc->desc, comm, &set) != NRAYS_OK) { std::fprintf(stderr, "nrays_scene_set_create: %s\n", last_error()); return 1; }
+        } else if (create(&sc->desc, &scene) != NRAYS_OK) { std::fprintf(stderr, "nrays_scene_create: %s\n", last_error()); return 1; }
         for (const Camera& c : sc->cameras) {
             NraysRenderParams p; std::memset(&p, 0, sizeof p);
             p.width = (uint32_t)(ow ? ow : (long)c.resolution[0]); p.height = (uint32_t)(oh ? oh : (long)c.resolution[1]);
@@ -59,9 +71,10 @@ int main(int argc, char** argv) {
             std::printf("Tracing %llu rays.\n", (unsigned long long)p.width * p.height * p.ray_per_pixel);
             std::vector<float> px((size_t)p.width * p.height * 3);
             auto t0 = std::chrono::steady_clock::now();
-            if (render(scene, &p, px.data()) != NRAYS_OK) { std::fprintf(stderr, "nrays_render: %s\n", last_error()); return 1; }
+            if ((set ? render_multi(set, &p, px.data()) : render(scene, &p, px.data())) != NRAYS_OK) { std::fprintf(stderr, "nrays_render: %s\n", last_error()); return 1; }
             double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-            NraysStats st; get_stats(scene, &st);
+            NraysStats st;
+            if (set) multi_stats(set, &st); else get_stats(scene, &st);
             unsigned long long rays = st.rays_primary + st.rays_reflection + st.rays_refraction + st.rays_shadow;
             std::printf("Rays cast. %llu rays in %.3f ms (%.1f Mrays/s incl. the device-to-host copy; GPU %.3f ms)\n", rays, ms, rays / ms / 1e3, st.kernel_ms_total);
             std::printf("Saving image to: %s\n", c.output.c_str());
@@ -69,7 +82,7 @@ int main(int argc, char** argv) {
             else { auto q = quantize_rgb8(px.data(), px.size()); write_png_rgb8(c.output, q.data(), p.width, p.height); }
             std::printf("Image saved.\n");
         }
-        destroy(scene);
+        if (set) { set_destroy(set); comm_destroy(comm); } else destroy(scene);
     } catch (const std::exception& e) { std::fprintf(stderr, "%s\n", e.what()); return 1; }
     return 0;
 }

@@ -141,7 +141,10 @@ Image8 read_png(const std::string& path) {
         uint32_t len = be32(&d[p]); std::string type((const char*)&d[p + 4], 4);
         if (p + 12 + len > d.size()) throw std::runtime_error("png: truncated chunk");
         const uint8_t* c = &d[p + 8];
-        if (type == "IHDR") { w = be32(c); h = be32(c + 4); depth = c[8]; ctype = c[9]; interlace = c[12]; }
+        if (type == "IHDR") {
+            if (len != 13) throw std::runtime_error("png: bad IHDR length: " + path);
+            w = be32(c); h = be32(c + 4); depth = c[8]; ctype = c[9]; interlace = c[12];
+        }
         else if (type == "PLTE") plte.assign(c, c + len);
         else if (type == "tRNS") trns.assign(c, c + len);
         else if (type == "IDAT") idat.insert(idat.end(), c, c + len);
@@ -151,6 +154,12 @@ Image8 read_png(const std::string& path) {
     if (!w || !h || interlace) throw std::runtime_error("png: unsupported (empty or interlaced): " + path);
     int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
     if (!ch) throw std::runtime_error("png: bad colour type");
+    // legal (colour type, bit depth) pairs of the PNG specification; anything else would give a zero or garbage stride
+    const bool depth_ok = ctype == 0 ? (depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16)
+                        : ctype == 3 ? (depth == 1 || depth == 2 || depth == 4 || depth == 8)
+                                     : (depth == 8 || depth == 16);
+    if (!depth_ok) throw std::runtime_error("png: bad bit depth for the colour type: " + path);
+    if ((uint64_t)w * h > (1ull << 28)) throw std::runtime_error("png: image too large: " + path);
     size_t bpp_bits = (size_t)ch * depth, stride = (w * bpp_bits + 7) / 8, bpp = std::max<size_t>(1, bpp_bits / 8);
     std::vector<uint8_t> raw = inflate_zlib(idat);
     if (raw.size() < (stride + 1) * h) throw std::runtime_error("png: short image data");
@@ -214,7 +223,7 @@ void write_png_rgb8(const std::string& path, const uint8_t* rgb, uint32_t w, uin
 // Image::to_png quantisation (src/image.rs:66-76): c*255, clamped to [0,255], truncated.
 std::vector<uint8_t> quantize_rgb8(const float* rgb, size_t n) {
     std::vector<uint8_t> q(n);
-    for (size_t i = 0; i < n; ++i) { float v = rgb[i] * 255.0f; v = v < 0.0f ? 0.0f : v; v = v > 255.0f ? 255.0f : v; q[i] = (uint8_t)(size_t)v; }
+    for (size_t i = 0; i < n; ++i) { float v = rgb[i] * 255.0f; v = (v > 0.0f) ? v : 0.0f /* NaN and negatives -> 0, as Rust's saturating `as` casts */; v = v > 255.0f ? 255.0f : v; q[i] = (uint8_t)(size_t)v; }
     return q;
 }
 

@@ -338,7 +338,10 @@ std::unique_ptr<LoadedScene> parse_scene(const std::string& text, const std::str
             NraysLight l; std::memset(&l, 0, sizeof l);
             for (int k = 0; k < 3; ++k) { l.pos[k] = props.pos[k]; l.color[k] = (float)props.color[k]; }
             l.radius = props.radius;
-            l.racsample = (uint32_t)std::sqrt((float)(size_t)props.nsample); // light.rs:20 with `nsample as usize` (loader3d.rs:456)
+            // light.rs:20 with `nsample as usize` (loader3d.rs:456): Rust's cast saturates (negative / NaN -> 0), a C++ cast
+            // of such a double is undefined
+            const size_t nsample = props.nsample > 0.0 ? (props.nsample < 4.0e9 ? (size_t)props.nsample : (size_t)4000000000u) : 0;
+            l.racsample = (uint32_t)std::sqrt((float)nsample);
             sc->lights.push_back(l);
         } else if (mode == CameraMode) {
             need(props.has_output, "output <filename>"); need(props.has_resolution, "resolution <x> <y>");

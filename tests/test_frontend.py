@@ -237,3 +237,42 @@ def test_every_shipped_reference_scene_file_parses(host, tmp_path):
             raise AssertionError("asset loop did not converge for " + sf)
         assert len(fs.cameras) >= 1 and fs.descriptor.pointer() is not None, sf
         fs.close()
+
+
+def _png_bytes(ihdr_payload, idat=b"\x00\x00"):
+    import struct
+    import zlib
+
+    def chunk(kind, data):
+        return struct.pack(">I", len(data)) + kind + data + struct.pack(">I", zlib.crc32(kind + data) & 0xFFFFFFFF)
+    return b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", ihdr_payload) + chunk(b"IDAT", zlib.compress(idat)) + chunk(b"IEND", b"")
+
+
+def test_malformed_png_headers_are_errors_not_crashes(host, tmp_path):
+    """a short IHDR, bit depth 0 (division by zero in the stride) or an illegal (colour type, depth) pair
+    must be reported, as must the loader's `Image not found`-style failures — never a crash."""
+    import struct
+    cases = {"short_ihdr.png": struct.pack(">II", 1, 1) + b"\x08\x02",                      # 10 bytes instead of 13
+             "depth0.png": struct.pack(">IIBBBBB", 1, 1, 0, 2, 0, 0, 0),
+             "depth3.png": struct.pack(">IIBBBBB", 1, 1, 3, 0, 0, 0, 0),
+             "rgb_depth4.png": struct.pack(">IIBBBBB", 1, 1, 4, 2, 0, 0, 0),
+             "palette16.png": struct.pack(">IIBBBBB", 1, 1, 16, 3, 0, 0, 0)}
+    for name, ihdr in cases.items():
+        p = tmp_path / name
+        p.write_bytes(_png_bytes(ihdr))
+        with pytest.raises(RuntimeError, match="png"):
+            scenefile.read_png(str(p))
+    ok = tmp_path / "ok.png"
+    ok.write_bytes(_png_bytes(struct.pack(">IIBBBBB", 1, 1, 8, 0, 0, 0, 0), b"\x00\x7f"))
+    assert scenefile.read_png(str(ok)).tolist() == [[[0x7f]]]
+
+
+def test_saturating_casts_of_the_reference(host, tmp_path):
+    """`nsample as usize` (loader3d.rs:456) and the u8 quantisation of image.rs:66-76 saturate in Rust: a negative
+    nsample gives racsample 0, a NaN / negative channel gives 0, anything above 1 gives 255."""
+    fs = scenefile.FileScene(_scene(tmp_path, "light\n pos 0 1 0\n color 1 1 1\n radius 0.5\n nsample -7\n"))
+    assert fs.descriptor.desc.lights[0].racsample == 0
+    img = np.array([[[np.nan, -1.0, 0.5], [2.0, 1.0, 0.0039]]], dtype=np.float32)
+    out = tmp_path / "q.png"
+    scenefile.write_png(str(out), img)
+    assert scenefile.read_png(str(out)).tolist() == [[[0, 0, 127], [255, 255, 0]]]
