@@ -10,8 +10,10 @@
  * (Cargo.toml:12-13, no Cargo.lock), whose sources are absent.  This file restates
  *   - nrays-owned arithmetic line by line (citations below are relative to /root/reference), and
  *   - the published ncollide3d/nalgebra algorithms as recalled in SURVEY.md Appendix B,
- * and is pinned only by analytic known-answer tests (tests/test_oracle_kat.py) and by
- * brute-force-vs-BVT equivalence.  Explicit deviations:
+ * and is pinned only by analytic known-answer tests (tests/test_oracle_kat.py), by fixtures derived
+ * independently of this file (60-digit membership bisection + support-map certificates,
+ * tests/golden/make_kat_independent.py, tests/test_kat_independent.py) and by brute-force-vs-BVT
+ * equivalence.  Explicit deviations:
  *   D-1  RNG is counter-based (the reference uses an OS-seeded thread RNG, scene.rs:75, light.rs:60);
  *   D-2  equal-toi ties are broken by smallest node index, then smallest triangle index
  *        (reference order is BinaryHeap dependent);
