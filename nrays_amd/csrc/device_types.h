@@ -177,8 +177,9 @@ struct DRender {
     uint32_t sample_begin, sample_end; // samples handled by this launch
     uint32_t max_depth;
     uint32_t band_rows, band_owner, band_owners;
-    uint32_t first_batch;        // 1: store into out, 0: add
+    uint32_t first_batch;        // 1: the frame starts here, 0: a later sample batch continues the running sums in `out`
     uint32_t use_rng;            // 0 when no random number can be consumed (window == 0, no area light)
+    uint32_t lane_log2;          // log2 of the lanes that share one pixel (sample-major mapping of AA frames; 0 = one lane per pixel)
     double window_width;
     double eye[3];
     double m[16];                // (P V)^-1 column-major

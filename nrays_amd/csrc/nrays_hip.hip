@@ -138,7 +138,14 @@ __global__ void __launch_bounds__(kBlock, waves_per_simd(FEAT)) k_primary(DScene
 #endif
 
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t nwt = tiles_x * tiles_y * 4u; // wave tiles: 4 per 16x16 block
+    // Sample-major lane mapping of anti-aliased frames (ray_per_pixel >= 2): 2^lane_log2 lanes share ONE pixel and trace
+    // its samples side by side, so a wave covers 64 >> lane_log2 pixels (8x4, 4x4, 4x2, 2x2, 2x1, 1x1) instead of 8x8 and
+    // its 64 rays start within a few pixels of each other — the coherence that thin geometry (hair: 16 % SIMD efficiency
+    // in the node loops at one lane per pixel) otherwise lacks.  The samples of a pixel are then summed in sample order
+    // (tot_c = tot_c + trace(ray), scene.rs:72-91) by an in-wave ordered reduction, so the frame is bit-identical to the
+    // pixel-major one.  One lane per pixel (lane_log2 = 0): wave tiles are 8x8, four per 16x16 block.
+    const uint32_t lane_log2 = PLAIN ? 0u : R.lane_log2;
+    const uint32_t nwt = lane_log2 ? tiles_x * tiles_y : tiles_x * tiles_y * 4u;
 
     // grab == 0 (cheap analytic scenes, ~1 us tiles): the wave tiles are dealt round-robin to the workgroups and
     // the four waves of a workgroup pull from their list through an LDS counter — list scheduling inside the
@@ -186,10 +193,20 @@ __global__ void __launch_bounds__(kBlock, waves_per_simd(FEAT)) k_primary(DScene
       }
       for (uint32_t wt = first; wt < last; ++wt) {
         const unsigned long long tile_t0 = R.tile_cost ? __builtin_readcyclecounter() : 0ULL;
-        uint32_t tile = wt >> 2, sub = wt & 3u;
-        uint32_t tx = tile % tiles_x, ty = tile / tiles_x;
-        uint32_t lx = ((sub & 1u) << 3) | (lane & 7u), ly = ((sub >> 1) << 3) | (lane >> 3);
-        uint32_t i = tx * kTile + lx, rl = ty * kTile + ly; // column, local (compact) row
+        uint32_t i, rl; // column, local (compact) row
+        uint32_t q = 0u; // which of the pixel's side-by-side samples this lane traces
+        if (lane_log2 == 0u) {
+            uint32_t tile = wt >> 2, sub = wt & 3u;
+            uint32_t tx = tile % tiles_x, ty = tile / tiles_x;
+            uint32_t lx = ((sub & 1u) << 3) | (lane & 7u), ly = ((sub >> 1) << 3) | (lane >> 3);
+            i = tx * kTile + lx; rl = ty * kTile + ly;
+        } else {
+            const uint32_t bwl = (7u - lane_log2) >> 1, bhl = (6u - lane_log2) >> 1; // the wave's pixel block is 2^bwl x 2^bhl
+            const uint32_t p = lane >> lane_log2;
+            q = lane & ((1u << lane_log2) - 1u);
+            uint32_t tx = wt % tiles_x, ty = wt / tiles_x;
+            i = (tx << bwl) + (p & ((1u << bwl) - 1u)); rl = (ty << bhl) + (p >> bwl);
+        }
         // local row -> global row (framebuffer bands dealt round-robin to owners)
         uint32_t j = rl;
         if (R.band_rows != 0 && R.band_owners > 1) {
@@ -203,26 +220,36 @@ __global__ void __launch_bounds__(kBlock, waves_per_simd(FEAT)) k_primary(DScene
         f3 tot = F3(0.0f, 0.0f, 0.0f);
         if (!PLAIN && !R.first_batch && active) { const float* o = out + (size_t)pix * 3; tot = F3(o[0], o[1], o[2]); }
         const uint32_t s_begin = PLAIN ? 0u : R.sample_begin, s_end = PLAIN ? 1u : R.sample_end;
-        for (uint32_t s = s_begin; s < s_end; ++s) {
+        for (uint32_t g = s_begin; g < s_end; g += 1u << lane_log2) {
+            const uint32_t s = g + q;
+            const bool sample_active = active && s < s_end;
             RayState ray;
             generate_primary<PLAIN>(R, i, j, s, pix, ray);
             unsigned node_before = cnt.node;
             f3 c;
-            if (__ballot(active && primary_may_hit(S, ray.o, ray.d)) == 0ULL) {
+            if (__ballot(sample_active && primary_may_hit(S, ray.o, ray.d)) == 0ULL) {
                 // no ray of this wave tile gets past the root of the BVT: Scene::trace returns the background for
                 // all of them (scene.rs:157-161), without entering the trace loop
                 c = F3(S.background[0], S.background[1], S.background[2]);
-                if (STATS && active && S.closest_root >= 0) cnt.node += root_children(S);
+                if (STATS && sample_active && S.closest_root >= 0) cnt.node += root_children(S);
             } else {
-                c = trace_chain<STATS, FEAT>(S, st, active, ray, 0u, R.max_depth, qo, cnt, !PLAIN && R.use_rng != 0u);
+                c = trace_chain<STATS, FEAT>(S, st, sample_active, ray, 0u, R.max_depth, qo, cnt, !PLAIN && R.use_rng != 0u);
             }
             if (STATS) { unsigned dn = cnt.node - node_before; if (dn > cnt.max_chain_nodes) cnt.max_chain_nodes = dn; }
-            tot.x = tot.x + c.x; tot.y = tot.y + c.y; tot.z = tot.z + c.z;
+            if (lane_log2 == 0u) { tot.x = tot.x + c.x; tot.y = tot.y + c.y; tot.z = tot.z + c.z; }
+            else { // the pixel's lanes hold samples g .. g + 2^lane_log2 - 1: add them in sample order (every lane of the group keeps the same sum)
+                const uint32_t base = lane & ~((1u << lane_log2) - 1u);
+                for (uint32_t k = 0; k < (1u << lane_log2) && g + k < s_end; ++k) { // wave-uniform bounds
+                    const float cx = __shfl(c.x, (int)(base + k)), cy = __shfl(c.y, (int)(base + k)), cz = __shfl(c.z, (int)(base + k));
+                    tot.x = tot.x + cx; tot.y = tot.y + cy; tot.z = tot.z + cz;
+                }
+            }
         }
-        if (active) {
+        if (active && q != 0u) { /* the group's first lane writes the pixel */ }
+        else if (active) {
             float* o = out + (size_t)pix * 3;
             o[0] = tot.x; o[1] = tot.y; o[2] = tot.z;
-        } else if (i < R.width && rl < R.rows_local && (PLAIN || R.first_batch)) { // padding rows of the last band
+        } else if (q == 0u && i < R.width && rl < R.rows_local && (PLAIN || R.first_batch)) { // padding rows of the last band
             float* o = out + (size_t)pix * 3;
             o[0] = 0.0f; o[1] = 0.0f; o[2] = 0.0f;
         }
@@ -392,6 +419,8 @@ struct NraysScene {
     bool have_last = false;
     // A/B and test switches, read ONCE when the handle is created (never in the frame path)
     uint64_t max_primary_per_launch = 32ull << 20; // NRAYS_MAX_PRIMARY: sample batching threshold (tests force several launches)
+    bool max_primary_forced = false;
+    int lane_log2_override = -1;                    // NRAYS_LANE_LOG2: cap of the lanes per pixel of AA frames (A/B)
     int grab_override = -1;                         // NRAYS_GRAB
     bool lpt_enabled = true;                        // NRAYS_LPT=0 restores image order
     NraysStats last;
@@ -494,12 +523,15 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
     if (npix_local >= (1ull << 31)) return fail(NRAYS_ERR_UNSUPPORTED, "tile too large");
 
     // sample batching keeps the number of primary rays (and hence continuation rays) per launch bounded
-    const uint64_t kMaxPrimaryPerLaunch = sc->max_primary_per_launch;
-    uint32_t batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(p->ray_per_pixel, kMaxPrimaryPerLaunch / std::max<uint64_t>(1, npix_local)));
-
     // Continuation rays stay in registers (trace_chain); the HBM queue is only needed when one hit can
     // spawn both a reflection and a refraction.
     const bool queued = sc->host.any_double_branch;
+    // Sample batching bounds the continuation rays one launch can append to that queue; a frame without a queue renders
+    // all its samples in ONE launch (NRAYS_MAX_PRIMARY forces batching for the tests).
+    const uint64_t kMaxPrimaryPerLaunch = sc->max_primary_per_launch;
+    uint32_t batch = (queued || sc->max_primary_forced)
+        ? (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(p->ray_per_pixel, kMaxPrimaryPerLaunch / std::max<uint64_t>(1, npix_local)))
+        : p->ray_per_pixel;
     if (queued) {
         uint64_t want = std::min<uint64_t>(std::max<uint64_t>(4 * npix_local * batch, 1u << 16), 1ull << 27);
         int rc = ensure_queue(sc, (uint32_t)want);
@@ -518,8 +550,14 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
     for (int a = 0; a < 16; ++a) R.m[a] = p->inv_proj_view[a];
     R.seed = p->seed;
 
-    const uint32_t tiles_x = (p->width + kTile - 1) / kTile, tiles_y = (rows + kTile - 1) / kTile;
-    const uint32_t ntiles = tiles_x * tiles_y;
+    // lanes per pixel of an anti-aliased frame (sample-major mapping, see k_primary): the largest power of two <= min(batch, 64)
+    uint32_t lane_log2 = 0;
+    if (batch >= 2) { while (lane_log2 < 6u && (2u << lane_log2) <= batch) ++lane_log2; }
+    if (sc->lane_log2_override >= 0) lane_log2 = std::min<uint32_t>((uint32_t)sc->lane_log2_override, lane_log2);
+    R.lane_log2 = lane_log2;
+    const uint32_t bwl = lane_log2 ? (7u - lane_log2) >> 1 : 4u, bhl = lane_log2 ? (6u - lane_log2) >> 1 : 4u; // pixel block of a scheduling unit
+    const uint32_t tiles_x = (p->width + (1u << bwl) - 1) >> bwl, tiles_y = (rows + (1u << bhl) - 1) >> bhl;
+    const uint32_t ntiles = lane_log2 ? (tiles_x * tiles_y + 3u) / 4u : tiles_x * tiles_y; // in units of four wave tiles
     uint32_t grab = sc->host.any_mesh ? 1u : 0u; // 0 = workgroup lists through LDS; the specialised kernels fix their path at compile time
     if (sc->grab_override >= 0) grab = (uint32_t)sc->grab_override; // tiles per dequeue of the mesh kernels, A/B only (NRAYS_GRAB); pixels do not depend on it
     // persistent grid: exactly the workgroups that can be resident (one 4-wave workgroup per CU per wave/SIMD)
@@ -562,7 +600,7 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
     bool lpt = grab >= 1u;
     lpt = lpt && sc->lpt_enabled; // A/B switch (NRAYS_LPT=0)
     if (lpt) {
-        const uint32_t nwt = ntiles * 4u;
+        const uint32_t nwt = lane_log2 ? tiles_x * tiles_y : ntiles * 4u;
         if (nwt > sc->tile_slots) {
             if (sc->d_tile_cost) { (void)hipFree(sc->d_tile_cost); sc->d_tile_cost = nullptr; }
             if (sc->d_tile_order) { (void)hipFree(sc->d_tile_order); sc->d_tile_order = nullptr; }
@@ -571,7 +609,7 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
             HIP_TRY(hipMalloc((void**)&sc->d_tile_order, (size_t)nwt * sizeof(uint32_t)));
             sc->tile_slots = nwt;
         }
-        const uint64_t key = ((uint64_t)p->width << 40) ^ ((uint64_t)rows << 20) ^ ((uint64_t)p->band_rows << 8) ^ ((uint64_t)p->band_owner << 4) ^ (uint64_t)R.band_owners;
+        const uint64_t key = ((uint64_t)p->width << 40) ^ ((uint64_t)rows << 20) ^ ((uint64_t)p->band_rows << 8) ^ ((uint64_t)p->band_owner << 4) ^ (uint64_t)R.band_owners ^ ((uint64_t)lane_log2 << 60);
         if (sc->cost_valid && sc->cost_key == key) {
             HIP_TRY(hipEventRecord(sc->ev_begin[slot], stream));
             sc->has_prepass[slot] = true;
@@ -701,7 +739,8 @@ int nrays_scene_create(const NraysSceneDesc* desc, NraysScene** out_scene) {
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, sc->device) == hipSuccess && cus > 0) sc->num_cus = cus;
     }
     sc->features = h.features ? h.features : kFeatAll;
-    if (const char* e = getenv("NRAYS_MAX_PRIMARY")) sc->max_primary_per_launch = (uint64_t)std::max(1ll, atoll(e));
+    if (const char* e = getenv("NRAYS_MAX_PRIMARY")) { sc->max_primary_per_launch = (uint64_t)std::max(1ll, atoll(e)); sc->max_primary_forced = true; }
+    if (const char* e = getenv("NRAYS_LANE_LOG2")) sc->lane_log2_override = std::max(0, std::min(6, atoi(e)));
     if (const char* e = getenv("NRAYS_GRAB")) sc->grab_override = std::max(0, atoi(e));
     if (const char* e = getenv("NRAYS_LPT")) sc->lpt_enabled = atoi(e) != 0;
     // release bulk host copies
