@@ -515,13 +515,18 @@ struct Hit {
 // f32 view of a ray for box culling.  The BVH bounds are exact f32 supersets of the f64 geometry; the
 // slab test runs in f32 with explicit error margins so that it is a SUPERSET of the f64 slab test
 // (ncollide ray_aabb, called at src/scene.rs:276) and can therefore never change a result:
-//   o32 = fl(o)            |o - o32| <= |o| 2^-24          -> absolute margin e = |o32 * inv32| 2^-22 per axis
+//   o32 = fl(o)            |o - o32| <= |o| 2^-24
 //   inv32 = rcp(fl(d))     relative error <= 2^-24 (rounding of d) + 2^-23 (v_rcp_f32, 1 ulp)
-//   t = fl(fl(b - o32) * inv32)  relative error <= 5 * 2^-24 = 3.0e-7 -> relative slack 2^-21 = 4.8e-7 on the final compare
+//   n = -fl(o32 * inv32)   one more rounding of |o inv|
+//   t = fma(b, inv32, n)   = fl((b - o32) inv32 + rounding of n): b inv32 and o32 inv32 share inv32, so its error stays
+//                          RELATIVE to t (3 * 2^-24, + 2^-24 for the fma's own rounding -> relative slack 2^-21 = 4.8e-7
+//                          on the final compare), while the roundings of o32 and of n are absolute, 2 * 2^-24 |o inv|
+//                          together -> absolute margin e = |o32 * inv32| 2^-22 per axis (twice that)
 // A zero direction component uses the finite inverse 1e30 (no NaN from 0 * inf; the margin then
 // decides inside/outside of the slab conservatively).
 struct RayF {
-    float ox, oy, oz, ix, iy, iz, ex, ey, ez;
+    float nx, ny, nz; // -(o32 * inv32): the slab distances are ONE fused multiply-add per plane, fma(b, inv32, n)
+    float ix, iy, iz, ex, ey, ez;
 };
 NR_DEV float inv_f32(double d) {
     float x = (float)d;
@@ -531,11 +536,13 @@ NR_DEV float inv_f32(double d) {
 }
 NR_DEV RayF make_rayf(d3 o, d3 d) {
     RayF r;
-    r.ox = (float)o.x; r.oy = (float)o.y; r.oz = (float)o.z;
+    const float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z;
     r.ix = inv_f32(d.x); r.iy = inv_f32(d.y); r.iz = inv_f32(d.z);
-    r.ex = fabsf(r.ox * r.ix) * 2.384185791015625e-07f; // 2^-22
-    r.ey = fabsf(r.oy * r.iy) * 2.384185791015625e-07f;
-    r.ez = fabsf(r.oz * r.iz) * 2.384185791015625e-07f;
+    const float px = ox * r.ix, py = oy * r.iy, pz = oz * r.iz;
+    r.nx = -px; r.ny = -py; r.nz = -pz;
+    r.ex = fabsf(px) * 2.384185791015625e-07f; // 2^-22
+    r.ey = fabsf(py) * 2.384185791015625e-07f;
+    r.ez = fabsf(pz) * 2.384185791015625e-07f;
     return r;
 }
 // Upper f32 bound of the current best distance (ties with it must still be visited).
@@ -543,9 +550,9 @@ NR_DEV float best_f32(double bt) { return (float)bt * 1.0000004f + 1e-37f; }
 
 // Returns the (approximate) entry distance, or -1 on a miss.
 NR_DEV float box_entry(float mnx, float mny, float mnz, float mxx, float mxy, float mxz, const RayF& r, float tbest) {
-    float x1 = (mnx - r.ox) * r.ix, x2 = (mxx - r.ox) * r.ix;
-    float y1 = (mny - r.oy) * r.iy, y2 = (mxy - r.oy) * r.iy;
-    float z1 = (mnz - r.oz) * r.iz, z2 = (mxz - r.oz) * r.iz;
+    float x1 = __builtin_fmaf(mnx, r.ix, r.nx), x2 = __builtin_fmaf(mxx, r.ix, r.nx);
+    float y1 = __builtin_fmaf(mny, r.iy, r.ny), y2 = __builtin_fmaf(mxy, r.iy, r.ny);
+    float z1 = __builtin_fmaf(mnz, r.iz, r.nz), z2 = __builtin_fmaf(mxz, r.iz, r.nz);
     float xn = fminf(x1, x2) - r.ex, xf = fmaxf(x1, x2) + r.ex;
     float yn = fminf(y1, y2) - r.ey, yf = fmaxf(y1, y2) + r.ey;
     float zn = fminf(z1, z2) - r.ez, zf = fmaxf(z1, z2) + r.ez;
@@ -557,20 +564,20 @@ NR_DEV float box_entry(float mnx, float mny, float mnz, float mxx, float mxy, fl
 // Four boxes at once (the SoA node layout of device_types.h): same arithmetic and margins as
 // box_entry, two children per packed-f32 instruction for the subtract / multiply / margin steps.
 typedef float f2 __attribute__((ext_vector_type(2)));
-NR_DEV void slab2(f2 mn, f2 mx, float o, float inv, float e, f2& tn, f2& tf) {
-    f2 a = (mn - o) * inv, b = (mx - o) * inv;
+NR_DEV void slab2(f2 mn, f2 mx, float n, float inv, float e, f2& tn, f2& tf) {
+    f2 a = __builtin_elementwise_fma(mn, f2{inv, inv}, f2{n, n}), b = __builtin_elementwise_fma(mx, f2{inv, inv}, f2{n, n});
     tn = __builtin_elementwise_min(a, b) - e;
     tf = __builtin_elementwise_max(a, b) + e;
 }
 NR_DEV void box_entry4(float4 mnx, float4 mny, float4 mnz, float4 mxx, float4 mxy, float4 mxz, const RayF& r, float tbest,
                        float& t0, float& t1, float& t2, float& t3) {
     f2 xn0, xf0, xn1, xf1, yn0, yf0, yn1, yf1, zn0, zf0, zn1, zf1;
-    slab2(f2{mnx.x, mnx.y}, f2{mxx.x, mxx.y}, r.ox, r.ix, r.ex, xn0, xf0);
-    slab2(f2{mnx.z, mnx.w}, f2{mxx.z, mxx.w}, r.ox, r.ix, r.ex, xn1, xf1);
-    slab2(f2{mny.x, mny.y}, f2{mxy.x, mxy.y}, r.oy, r.iy, r.ey, yn0, yf0);
-    slab2(f2{mny.z, mny.w}, f2{mxy.z, mxy.w}, r.oy, r.iy, r.ey, yn1, yf1);
-    slab2(f2{mnz.x, mnz.y}, f2{mxz.x, mxz.y}, r.oz, r.iz, r.ez, zn0, zf0);
-    slab2(f2{mnz.z, mnz.w}, f2{mxz.z, mxz.w}, r.oz, r.iz, r.ez, zn1, zf1);
+    slab2(f2{mnx.x, mnx.y}, f2{mxx.x, mxx.y}, r.nx, r.ix, r.ex, xn0, xf0);
+    slab2(f2{mnx.z, mnx.w}, f2{mxx.z, mxx.w}, r.nx, r.ix, r.ex, xn1, xf1);
+    slab2(f2{mny.x, mny.y}, f2{mxy.x, mxy.y}, r.ny, r.iy, r.ey, yn0, yf0);
+    slab2(f2{mny.z, mny.w}, f2{mxy.z, mxy.w}, r.ny, r.iy, r.ey, yn1, yf1);
+    slab2(f2{mnz.x, mnz.y}, f2{mxz.x, mxz.y}, r.nz, r.iz, r.ez, zn0, zf0);
+    slab2(f2{mnz.z, mnz.w}, f2{mxz.z, mxz.w}, r.nz, r.iz, r.ez, zn1, zf1);
     float n0 = fmaxf(fmaxf(xn0.x, yn0.x), fmaxf(zn0.x, 0.0f)), f0 = fminf(fminf(xf0.x, yf0.x), fminf(zf0.x, tbest));
     float n1 = fmaxf(fmaxf(xn0.y, yn0.y), fmaxf(zn0.y, 0.0f)), f1 = fminf(fminf(xf0.y, yf0.y), fminf(zf0.y, tbest));
     float n2 = fmaxf(fmaxf(xn1.x, yn1.x), fmaxf(zn1.x, 0.0f)), f2_ = fminf(fminf(xf1.x, yf1.x), fminf(zf1.x, tbest));
