@@ -127,9 +127,9 @@ __global__ void __launch_bounds__(kBlock, waves_per_simd(FEAT)) k_primary(DScene
         if (zero_ctr && threadIdx.x < sizeof(DeviceCounters) / 4) ((uint32_t*)zero_ctr)[threadIdx.x] = 0u;
     }
     Stack st;
-    st.lds = lds_stack + threadIdx.x;
+    st.lds = (lds_u32*)(lds_stack + threadIdx.x);
     st.spill_stride = gridDim.x * kBlock;
-    st.spill = spill ? spill + (size_t)blockIdx.x * kBlock + threadIdx.x : nullptr;
+    st.spill = spill ? (global_u32*)(spill + (size_t)blockIdx.x * kBlock + threadIdx.x) : nullptr;
     st.sp = 0;
     Cnt cnt; cnt.node = cnt.tri = cnt.prim = cnt.hit = cnt.tex = cnt.shadow = cnt.refl = cnt.refr = cnt.max_depth = cnt.max_chain_nodes = 0;
 #ifdef NR_PHASE_TIMING
@@ -272,9 +272,9 @@ __global__ void __launch_bounds__(kBlock, NRAYS_WAVES_PER_SIMD) k_bounce(DScene 
                                                     uint32_t max_depth) {
     __shared__ uint32_t lds_stack[kLdsStack * kBlock];
     Stack st;
-    st.lds = lds_stack + threadIdx.x;
+    st.lds = (lds_u32*)(lds_stack + threadIdx.x);
     st.spill_stride = gridDim.x * kBlock;
-    st.spill = spill ? spill + (size_t)blockIdx.x * kBlock + threadIdx.x : nullptr;
+    st.spill = spill ? (global_u32*)(spill + (size_t)blockIdx.x * kBlock + threadIdx.x) : nullptr;
     st.sp = 0;
     Cnt cnt; cnt.node = cnt.tri = cnt.prim = cnt.hit = cnt.tex = cnt.shadow = cnt.refl = cnt.refr = cnt.max_depth = cnt.max_chain_nodes = 0;
 #ifdef NR_PHASE_TIMING

@@ -104,9 +104,11 @@ struct Cnt {
 // ---------------------------------------------------------------- traversal stack ------------
 // Entries 0..kLdsStack-1 live in LDS, laid out [entry][lane] so a wave's access is conflict-free
 // (stride-1 dwords across lanes); deeper entries spill to a per-lane column in HBM.
+typedef __attribute__((address_space(3))) uint32_t lds_u32;    // explicitly LDS: ds_read / ds_write, never a generic flat access
+typedef __attribute__((address_space(1))) uint32_t global_u32; // explicitly global memory
 struct Stack {
-    uint32_t* lds;   // &lds_stack[threadIdx.x]
-    uint32_t* spill; // &spill[global lane]   (may be null when the tree depth fits in LDS)
+    lds_u32* lds;      // &lds_stack[threadIdx.x]
+    global_u32* spill; // &spill[global lane]   (may be null when the tree depth fits in LDS)
     uint32_t spill_stride;
     int sp;
     NR_DEV void push(int32_t v) {
@@ -116,8 +118,13 @@ struct Stack {
     }
     NR_DEV int32_t pop() {
         --sp;
-        if (sp < kLdsStack) return (int32_t)lds[sp * kBlock];
-        return (int32_t)spill[(size_t)(sp - kLdsStack) * spill_stride];
+        // The LDS read is unconditional (clamped slot) and the HBM column only overrides it in its own, rare branch:
+        // written as `sp < kLdsStack ? lds[..] : spill[..]` the compiler selects between the two POINTERS and issues
+        // one generic flat_load — on the critical path of the node loop, counted against vmcnt and lgkmcnt alike.
+        // (`volatile`: the optimiser otherwise sinks this read below the branch and merges the two loads again.)
+        int32_t v = (int32_t)*(volatile lds_u32*)&lds[(sp < kLdsStack ? sp : kLdsStack - 1) * kBlock];
+        if (__builtin_expect(sp >= kLdsStack, 0)) v = (int32_t)spill[(size_t)(sp - kLdsStack) * spill_stride];
+        return v;
     }
 };
 
@@ -415,9 +422,16 @@ NR_DEV void load_xform(const Instance& in, Xform& m) {
 // One out-of-line copy shared by the closest-hit and shadow paths.  The record is RETURNED (56 bytes: the
 // AMDGPU calling convention hands aggregates of up to 16 dwords back in VGPRs); an `Isect&` out-parameter
 // would live in scratch memory and cost a store + load round trip per call.
-__device__ __noinline__ Isect cast_analytic(const Instance& in, d3 o, d3 d) {
+// The instance comes as an explicitly GLOBAL pointer: across the call boundary a plain reference is a generic pointer
+// and every field read a flat_load.
+typedef const __attribute__((address_space(1))) Instance* GInstance;
+__device__ __noinline__ Isect cast_analytic(GInstance inp, d3 o, d3 d) {
+    const __attribute__((address_space(1))) Instance& in = *inp;
     bool solid = (in.flags & kInstSolid) != 0;
-    Xform m; load_xform(in, m);
+    Xform m;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) m.r[k] = in.rot[k];
+    m.t = D3(in.trans[0], in.trans[1], in.trans[2]);
     Isect out;
     out.toi = 0.0; out.n = D3(0.0, 0.0, 0.0); out.u = 0.0; out.v = 0.0; out.has_uv = false; out.hit = false;
     switch (in.kind) {
@@ -436,12 +450,14 @@ __device__ __noinline__ Isect cast_analytic(const Instance& in, d3 o, d3 d) {
 NR_DEV f4 tex_at(const ShadeTex& t, uint32_t x, uint32_t y) {
     size_t i = (size_t)y * t.width + x;
     f4 r;
+    // the texel pointers live in device records: tell the compiler that they point to global memory (a generic
+    // pointer loaded from memory makes every fetch a flat_load)
     if ((t.mode & 0xffu) == NRAYS_TEXEL_RGBA8) {
-        uchar4 p = ((const uchar4*)t.texels)[i];
-        r.x = (float)p.x / 255.0f; r.y = (float)p.y / 255.0f; r.z = (float)p.z / 255.0f; r.w = (float)p.w / 255.0f;
+        const uint32_t p = ((const __attribute__((address_space(1))) uint32_t*)t.texels)[i]; // r | g << 8 | b << 16 | a << 24
+        r.x = (float)(p & 0xffu) / 255.0f; r.y = (float)((p >> 8) & 0xffu) / 255.0f; r.z = (float)((p >> 16) & 0xffu) / 255.0f; r.w = (float)(p >> 24) / 255.0f;
     } else {
-        float4 p = ((const float4*)t.texels)[i];
-        r.x = p.x; r.y = p.y; r.z = p.z; r.w = p.w;
+        const __attribute__((address_space(1))) float* p = (const __attribute__((address_space(1))) float*)t.texels + 4 * i;
+        r.x = p[0]; r.y = p[1]; r.z = p[2]; r.w = p[3];
     }
     return r;
 }
@@ -652,7 +668,7 @@ template <bool SHADOW, int FEAT, bool CHECK = false>
 NR_DEV bool resolve_hit(const DScene& S, d3 o, d3 d, const Hit& h, Isect& out, uint32_t& node_id) {
     const Instance& in = (SHADOW ? S.shadow_instances : S.instances)[h.inst];
     if ((FEAT & kFeatAnalytic) && (!(FEAT & kFeatMesh) || in.kind != NRAYS_SHAPE_TRIMESH)) {
-        out = cast_analytic(in, o, d);
+        out = cast_analytic((GInstance)&in, o, d);
         node_id = (uint32_t)in.node_id;
         return !CHECK || in.kind == NRAYS_SHAPE_PLANE || node_aabb_pass(S, node_id, o, d);
     }
@@ -847,7 +863,7 @@ NR_DEV bool traverse(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, Hit&
         if (kAnalytic) { // TLAS leaf: an analytic shape (or a plane pseudo-leaf)
             const Instance& in = insts[first];
             if (STATS) cnt.prim++;
-            Isect is = cast_analytic(in, o, d);
+            Isect is = cast_analytic((GInstance)&in, o, d);
             if (is.hit && (!GATED || in.kind == NRAYS_SHAPE_PLANE || node_aabb_pass(S, (uint32_t)in.node_id, o, d))) {
                 if (SHADOW) {
                     if (is.toi <= tlimit) {
