@@ -129,7 +129,7 @@ struct DeviceCounters {
     unsigned int max_depth; // deepest trace depth reached (= number of continuation generations)
     unsigned int max_chain_nodes; // instrumented: most AABB tests spent on one pixel's chain
     unsigned int pad;
-    unsigned long long dbg[4];    // tuning builds (NR_PHASE_TIMING): wave / lane iteration counts of the node loops and triangle leaves
+    unsigned long long dbg[8];    // tuning builds (NR_PHASE_TIMING): wave / lane iteration counts of the node loops and triangle leaves, cycles per query class, wave-uniform node iterations
 };
 
 constexpr int kMaxGenerations = 64; // hard cap on trace depth (reference recursion is unbounded, scene.rs:246)

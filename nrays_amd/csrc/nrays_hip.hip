@@ -76,6 +76,10 @@ __device__ __forceinline__ void flush_counters(DeviceCounters* ctr, const Cnt& c
     unsigned pn = c.cyc_node, pl = c.cyc_leaf, pt = c.cyc_tri; // accumulators only advance in active lanes: take the max over the wave
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { unsigned a = __shfl_down(pn, off), b = __shfl_down(pl, off), t = __shfl_down(pt, off); pn = a > pn ? a : pn; pl = b > pl ? b : pl; pt = t > pt ? t : pt; }
+    unsigned q0 = c.cyc_closest0, q1 = c.cyc_closestN, q2 = c.cyc_shadow, u0 = c.wv_uni;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { unsigned a = __shfl_down(q0, off), b = __shfl_down(q1, off), d = __shfl_down(q2, off); q0 = a > q0 ? a : q0; q1 = b > q1 ? b : q1; q2 = d > q2 ? d : q2; u0 += __shfl_down(u0, off); }
+    if (__lane_id() == 0) { atomicAdd(&ctr->dbg[4], (unsigned long long)q0); atomicAdd(&ctr->dbg[5], (unsigned long long)q1); atomicAdd(&ctr->dbg[6], (unsigned long long)q2); atomicAdd(&ctr->dbg[7], (unsigned long long)u0); }
     unsigned i0 = c.wv_node, i1 = c.ln_node, i2 = c.wv_tri, i3 = c.ln_tri;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { i0 += __shfl_down(i0, off); i1 += __shfl_down(i1, off); i2 += __shfl_down(i2, off); i3 += __shfl_down(i3, off); }
@@ -133,7 +137,7 @@ __global__ void __launch_bounds__(kBlock, waves_per_simd(FEAT)) k_primary(DScene
     st.sp = 0;
     Cnt cnt; cnt.node = cnt.tri = cnt.prim = cnt.hit = cnt.tex = cnt.shadow = cnt.refl = cnt.refr = cnt.max_depth = cnt.max_chain_nodes = 0;
 #ifdef NR_PHASE_TIMING
-    cnt.cyc_node = cnt.cyc_leaf = cnt.cyc_other = cnt.cyc_tri = 0; cnt.wv_node = cnt.ln_node = cnt.wv_tri = cnt.ln_tri = 0;
+    cnt.cyc_node = cnt.cyc_leaf = cnt.cyc_other = cnt.cyc_tri = 0; cnt.wv_node = cnt.ln_node = cnt.wv_tri = cnt.ln_tri = 0; cnt.cyc_closest0 = cnt.cyc_closestN = cnt.cyc_shadow = 0; cnt.wv_uni = 0;
     unsigned long long twave = __builtin_readcyclecounter();
 #endif
 
@@ -278,7 +282,7 @@ __global__ void __launch_bounds__(kBlock, NRAYS_WAVES_PER_SIMD) k_bounce(DScene 
     st.sp = 0;
     Cnt cnt; cnt.node = cnt.tri = cnt.prim = cnt.hit = cnt.tex = cnt.shadow = cnt.refl = cnt.refr = cnt.max_depth = cnt.max_chain_nodes = 0;
 #ifdef NR_PHASE_TIMING
-    cnt.cyc_node = cnt.cyc_leaf = cnt.cyc_other = cnt.cyc_tri = 0; cnt.wv_node = cnt.ln_node = cnt.wv_tri = cnt.ln_tri = 0;
+    cnt.cyc_node = cnt.cyc_leaf = cnt.cyc_other = cnt.cyc_tri = 0; cnt.wv_node = cnt.ln_node = cnt.wv_tri = cnt.ln_tri = 0; cnt.cyc_closest0 = cnt.cyc_closestN = cnt.cyc_shadow = 0; cnt.wv_uni = 0;
 #endif
     uint32_t n = *count_in;
     if (n > capacity) n = capacity;
@@ -837,12 +841,12 @@ int nrays_get_stats(NraysScene* sc, NraysStats* out) {
 
 #ifdef NR_PHASE_TIMING
 // Tuning builds only (tools/phase_timing.py): wave / lane iteration counts of the node loops and the triangle loops.
-int nrays_debug_counters(NraysScene* sc, unsigned long long out[4]) {
+int nrays_debug_counters(NraysScene* sc, unsigned long long out[8]) {
     if (!sc || !sc->have_last) return NRAYS_ERR_BAD_ARG;
     HIP_TRY(hipStreamSynchronize(sc->last_stream));
     DeviceCounters c;
     HIP_TRY(hipMemcpy(&c, sc->d_counters, sizeof c, hipMemcpyDeviceToHost));
-    for (int k = 0; k < 4; ++k) out[k] = c.dbg[k];
+    for (int k = 0; k < 8; ++k) out[k] = c.dbg[k];
     return NRAYS_OK;
 }
 #endif

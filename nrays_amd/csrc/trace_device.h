@@ -84,11 +84,13 @@ constexpr unsigned long long kSaltPath = 2ULL, kSaltRefl = 0x100ULL, kSaltRefr =
 // wave to traversal phases; lane 0 accumulates, flush_counters sums over waves.
 #define NR_TIC(var) unsigned long long var = __builtin_readcyclecounter()
 #define NR_ITER(wv, ln) { cnt.ln++; if ((int)__lane_id() == __ffsll((long long)__ballot(1)) - 1) cnt.wv++; }
+#define NR_UNIFORM(curv) { const int f_ = __builtin_amdgcn_readfirstlane(curv); const unsigned long long a_ = __ballot(1); if (__ballot((curv) != f_) == 0ULL && (int)__lane_id() == __ffsll((long long)a_) - 1) cnt.wv_uni++; }
 #define NR_TOC(cntfield, var) { unsigned long long now_ = __builtin_readcyclecounter(); cnt.cntfield += (unsigned)(now_ - var); var = now_; }
 #else
 #define NR_TIC(var)
 #define NR_TOC(cntfield, var)
 #define NR_ITER(wv, ln)
+#define NR_UNIFORM(curv)
 #endif
 struct Cnt {
     unsigned node, tri, prim, hit, tex;     // instrumented builds only
@@ -98,6 +100,8 @@ struct Cnt {
 #ifdef NR_PHASE_TIMING
     unsigned cyc_node, cyc_leaf, cyc_other, cyc_tri; // per-wave cycles (valid in lane 0); cyc_tri is part of cyc_leaf
     unsigned wv_node, ln_node, wv_tri, ln_tri;       // iterations of the node loop / triangle loop: per wave (counted by the leading active lane) and per lane
+    unsigned wv_uni;                                 // node-loop wave iterations in which every active lane fetches the SAME node
+    unsigned cyc_closest0, cyc_closestN, cyc_shadow; // wave cycles inside the closest-hit query of primary rays / of continuation rays / inside shadow queries
 #endif
 };
 
@@ -765,6 +769,7 @@ NR_DEV bool traverse(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, Hit&
             float4 mnx = q[0], mny = q[1], mnz = q[2], mxx = q[3], mxy = q[4], mxz = q[5];
             int4 ch = ((const int4*)q)[6];
             NR_ITER(wv_node, ln_node);
+            NR_UNIFORM(cur);
             // SURVEY 8d counts AABB tests: only the boxes that exist (an absent child slot is not a test)
             if (STATS) cnt.node += (unsigned)(ch.x != kEmptyChild) + (unsigned)(ch.y != kEmptyChild) + (unsigned)(ch.z != kEmptyChild) + (unsigned)(ch.w != kEmptyChild);
             float t0, t1, t2, t3;
@@ -952,7 +957,10 @@ NR_MAT_ATTR f4 material_compute(const DScene& S, Stack& st, const ShadeRec& m, c
                 filter = pre_filter;
             } else {
                 cnt.shadow++;
-                if (shadow_query<STATS, FEAT>(S, st, so, ldir, dist, filter, cnt)) continue; // shadowed
+                NR_TIC(tsq);
+                const bool blocked = shadow_query<STATS, FEAT>(S, st, so, ldir, dist, filter, cnt);
+                NR_TOC(cyc_shadow, tsq);
+                if (blocked) continue; // shadowed
             }
             double dot_ldir_norm = dot(ldir, normal);
             float dcoeff = (float)dot_ldir_norm;
@@ -1032,7 +1040,12 @@ NR_DEV f3 shade_hit(const DScene& S, Stack& st, RayState& ray, uint32_t depth, u
     bool gated = false;
     bool pre = false, pre_lit = false; f3 pre_filter = F3(1.0f, 1.0f, 1.0f);
     for (;;) { // second iteration only when the ungated winner fails the reference's AABB gates (knife-edge rays)
-        if (!traverse<false, STATS, FEAT>(S, st, ray.o, ray.d, kDblMax, hit, nofilter, cnt, gated, &is))
+        NR_TIC(tq);
+        const bool any_hit = traverse<false, STATS, FEAT>(S, st, ray.o, ray.d, kDblMax, hit, nofilter, cnt, gated, &is);
+#ifdef NR_PHASE_TIMING
+        if (depth == 0u) { NR_TOC(cyc_closest0, tq); } else { NR_TOC(cyc_closestN, tq); }
+#endif
+        if (!any_hit)
             return F3(S.background[0] * ray.weight, S.background[1] * ray.weight, S.background[2] * ray.weight);
         if (!(FEAT & kFeatMesh)) { // `is` is the winner's record already; only the deferred AABB gate is left
             const Instance& in = S.instances[hit.inst];
@@ -1059,7 +1072,9 @@ NR_DEV f3 shade_hit(const DScene& S, Stack& st, RayState& ray, uint32_t depth, u
             ldir = ldir / nrm;
             cnt.shadow++;
             pre = true;
+            NR_TIC(tsq);
             pre_lit = !shadow_query<STATS, FEAT>(S, st, point + ldir * 0.001, ldir, nrm - 0.001, pre_filter, cnt);
+            NR_TOC(cyc_shadow, tsq);
         }
     }
     is.toi = hit.t;
