@@ -206,11 +206,16 @@ int nrays_scene_set_create(const NraysSceneDesc* desc, NraysComm* comm, NraysSce
     return NRAYS_OK;
 }
 
+// Floats of one owner's compact tile for this frame (every owner's tile has the same, padded, size).
+static size_t tile_floats_of(const NraysSceneSet* s, const NraysRenderParams* p) {
+    NraysRenderParams q = *p;
+    q.band_rows = s->comm->owners > 1 ? kBandRows : 0; q.band_owner = 0; q.band_owners = s->comm->owners;
+    return (size_t)nrays_tile_rows(&q) * p->width * 3;
+}
+
 static int ensure_buffers(NraysSceneSet* s, const NraysRenderParams* p) {
     const uint32_t owners = s->comm->owners;
-    NraysRenderParams q = *p;
-    q.band_rows = owners > 1 ? kBandRows : 0; q.band_owner = 0; q.band_owners = owners;
-    const size_t tile_floats = (size_t)nrays_tile_rows(&q) * p->width * 3;
+    const size_t tile_floats = tile_floats_of(s, p);
     if (tile_floats > s->tile_floats) {
         for (auto& o : s->local) {
             MG_HIP(hipSetDevice(o.device));
@@ -251,7 +256,7 @@ int nrays_render_multi_device(NraysSceneSet* s, const NraysRenderParams* params,
     int rc = ensure_buffers(s, params);
     if (rc != NRAYS_OK) return rc;
     const int slot = (int)(s->step & 1u);
-    const size_t count = s->tile_floats; // every owner's compact tile has the same (padded) size
+    const size_t count = tile_floats_of(s, params); // this frame's tile size (the buffers may be larger: they only grow)
 
     // 1. tile renders, each on its owner's render stream
     for (auto& o : s->local) {

@@ -66,6 +66,21 @@ def test_pipelined_device_frames_and_aa(gpu):
     lib.nrays_comm_destroy(comm)
 
 
+def test_one_set_many_resolutions(gpu):
+    """The set's tile / gather buffers only grow: a smaller frame after a larger one must still be exchanged with ITS tile
+    size (and a larger one after that must re-allocate while nothing is in flight)."""
+    lib = abi.load_hip_lib()
+    sc, cam = su.balls_scene(tex_size=(64, 32))
+    comm = tiling.local_comm(3, [0, 0, 0])
+    ss = tiling.SceneSet(sc.descriptor, comm)
+    for (w, h) in [(320, 200), (96, 50), (33, 17), (400, 300), (96, 50)]:
+        p, _ = su.camera_params(cam, w, h)
+        ref, _ = _single(sc, p)
+        assert np.array_equal(ss.render(p), ref), (w, h)
+    ss.close()
+    lib.nrays_comm_destroy(comm)
+
+
 def test_ranked_communicator_one_rank_and_errors(gpu):
     lib = abi.load_hip_lib()
     uid = tiling.unique_id()
