@@ -182,7 +182,8 @@ typedef struct NraysStats {
     uint32_t instrumented;    /* 1 if the traversal counters above are valid */
     double kernel_ms_primary; /* mean GPU time of the primary kernel launch (HIP events on the render stream) */
     double kernel_ms_total;   /* mean GPU time of a whole render, first launch to last */
-    uint32_t frames_timed;    /* renders averaged in the two figures above (since the previous get_stats) */
+    uint32_t frames_timed;    /* renders averaged in the two figures above (since the previous get_stats): the events
+                                 are recorded on every 4th render of a handle and on every instrumented one */
     uint32_t reserved;
 } NraysStats;
 

@@ -425,6 +425,12 @@ struct NraysScene {
     uint64_t max_primary_per_launch = 32ull << 20; // NRAYS_MAX_PRIMARY: sample batching threshold (tests force several launches)
     bool max_primary_forced = false;
     int lane_log2_override = -1;                    // NRAYS_LANE_LOG2: cap of the lanes per pixel of AA frames (A/B)
+    // The HIP events behind NraysStats::kernel_ms_* are recorded on every 4th frame of a handle (and on every instrumented
+    // one): three event records per frame cost ~6 us of a 85 us frame (balls: 0.0849 -> 0.0789 ms per step); the averages
+    // nrays_get_stats reports are over the sampled frames.  NRAYS_EVENT_STRIDE overrides it (1 = every frame).
+    uint32_t event_stride = 4;
+    uint64_t frames_total = 0;
+    bool last_timed = true;
     int grab_override = -1;                         // NRAYS_GRAB
     bool lpt_enabled = true;                        // NRAYS_LPT=0 restores image order
     NraysStats last;
@@ -573,7 +579,12 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
 
     // All per-handle state (double-buffered counters, queues, raygen tables, tile costs) assumes that the renders of one
     // handle execute one after the other: a render on a different stream than its predecessor is ordered behind it.
-    if (sc->have_last && sc->last_stream != stream && sc->last_done) HIP_TRY(hipStreamWaitEvent(stream, sc->last_done, 0));
+    if (sc->have_last && sc->last_stream != stream) {
+        if (sc->last_timed && sc->last_done) HIP_TRY(hipStreamWaitEvent(stream, sc->last_done, 0));
+        else HIP_TRY(hipStreamSynchronize(sc->last_stream)); // the previous frame recorded no event to wait on
+    }
+    const bool timed = instrumented || (sc->frames_total % sc->event_stride) == 0;
+    sc->frames_total++;
     const int slot = (int)(sc->frames_recorded % NraysScene::kRing);
     // events: [pbegin .. pend] brackets the first primary launch; the frame spans [pbegin .. end], and
     // `end` is only recorded separately when something follows the primary kernel
@@ -615,7 +626,7 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
         }
         const uint64_t key = ((uint64_t)p->width << 40) ^ ((uint64_t)rows << 20) ^ ((uint64_t)p->band_rows << 8) ^ ((uint64_t)p->band_owner << 4) ^ (uint64_t)R.band_owners ^ ((uint64_t)lane_log2 << 60);
         if (sc->cost_valid && sc->cost_key == key) {
-            HIP_TRY(hipEventRecord(sc->ev_begin[slot], stream));
+            if (timed) HIP_TRY(hipEventRecord(sc->ev_begin[slot], stream));
             sc->has_prepass[slot] = true;
             hipLaunchKernelGGL(k_tile_order, dim3(8), dim3(1024), 0, stream, sc->d_tile_cost, sc->d_tile_order, nwt);
             HIP_TRY(hipGetLastError());
@@ -634,11 +645,11 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
         sc->launch_index++;
         QueueOut qo; qo.q = sc->queue[1].q; qo.capacity = queued ? sc->queue_capacity : 0; qo.count = sc->d_counts + 1;
         qo.overflow = &sc->d_counters->overflow;
-        if (first_primary) HIP_TRY(hipEventRecord(sc->ev_pbegin[slot], stream));
+        if (first_primary && timed) HIP_TRY(hipEventRecord(sc->ev_pbegin[slot], stream));
         launch_primary(instrumented, sc->features, grid_primary, stream, sc->d, R, qo, d_out, sc->d_counters, sc->d_spill, tiles_x, tiles_y, sc->d_counts + kMaxGenerations + 2, grab, next_counts, R.first_batch ? next_ctr : nullptr);
         HIP_TRY(hipGetLastError());
         if (first_primary) {
-            HIP_TRY(hipEventRecord(sc->ev_pend[slot], stream));
+            if (timed) HIP_TRY(hipEventRecord(sc->ev_pend[slot], stream));
             if (instrumented) HIP_TRY(hipMemcpyAsync(sc->d_counters_primary, sc->d_counters, sizeof(DeviceCounters), hipMemcpyDeviceToDevice, stream));
             first_primary = false;
         }
@@ -662,10 +673,13 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
         hipLaunchKernelGGL(k_resolve, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_out, n, (float)p->ray_per_pixel);
         HIP_TRY(hipGetLastError());
     }
-    if (!single_launch) HIP_TRY(hipEventRecord(sc->ev_end[slot], stream));
-    sc->single_launch[slot] = single_launch;
-    sc->last_done = single_launch ? sc->ev_pend[slot] : sc->ev_end[slot];
-    sc->frames_recorded++;
+    if (!single_launch && timed) HIP_TRY(hipEventRecord(sc->ev_end[slot], stream));
+    sc->last_timed = timed;
+    if (timed) {
+        sc->single_launch[slot] = single_launch;
+        sc->last_done = single_launch ? sc->ev_pend[slot] : sc->ev_end[slot];
+        sc->frames_recorded++;
+    }
     sc->last_stream = stream; sc->have_last = true;
     // owned rows only (padding rows of the last band carry no rays)
     uint64_t owned_rows = 0;
@@ -745,6 +759,7 @@ int nrays_scene_create(const NraysSceneDesc* desc, NraysScene** out_scene) {
     sc->features = h.features ? h.features : kFeatAll;
     if (const char* e = getenv("NRAYS_MAX_PRIMARY")) { sc->max_primary_per_launch = (uint64_t)std::max(1ll, atoll(e)); sc->max_primary_forced = true; }
     if (const char* e = getenv("NRAYS_LANE_LOG2")) sc->lane_log2_override = std::max(0, std::min(6, atoi(e)));
+    if (const char* e = getenv("NRAYS_EVENT_STRIDE")) sc->event_stride = (uint32_t)std::max(1, atoi(e));
     if (const char* e = getenv("NRAYS_GRAB")) sc->grab_override = std::max(0, atoi(e));
     if (const char* e = getenv("NRAYS_LPT")) sc->lpt_enabled = atoi(e) != 0;
     // release bulk host copies
@@ -840,6 +855,15 @@ int nrays_get_stats(NraysScene* sc, NraysStats* out) {
 }
 
 #ifdef NR_PHASE_TIMING
+// Tuning builds only (tools/tile_costs.py): the per-wave-tile cycle counts (>> 4) of the last mesh frame.
+int nrays_debug_tile_costs(NraysScene* sc, uint32_t* out, uint32_t capacity, uint32_t* out_count) {
+    if (!sc || !sc->have_last || !sc->d_tile_cost) return NRAYS_ERR_BAD_ARG;
+    HIP_TRY(hipStreamSynchronize(sc->last_stream));
+    const uint32_t n = std::min(capacity, sc->tile_slots);
+    HIP_TRY(hipMemcpy(out, sc->d_tile_cost, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    *out_count = n;
+    return NRAYS_OK;
+}
 // Tuning builds only (tools/phase_timing.py): wave / lane iteration counts of the node loops and the triangle loops.
 int nrays_debug_counters(NraysScene* sc, unsigned long long out[8]) {
     if (!sc || !sc->have_last) return NRAYS_ERR_BAD_ARG;

@@ -1,0 +1,29 @@
+#!/usr/bin/env python
+"""How concentrated a mesh frame's work is: distribution of the per-wave-tile cycle counts k_primary records for the
+cost-ordered work lists.  Needs a -DNR_PHASE_TIMING build (exports nrays_debug_tile_costs).
+  NRAYS_HIP_LIB=nrays_amd/lib/ab/lib_pt.so python tools/tile_costs.py sponza hairball"""
+import ctypes as C, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+from nrays_amd import abi
+from tests import scenes_util as su, standins
+lib = abi.load_hip_lib()
+for name in sys.argv[1:] or ["sponza"]:
+    sc, cam = {"sponza": standins.sponza_scene, "hairball": standins.hairball_scene, "sponza8": lambda: standins.sponza_scene(n_lights=8)}[name]()
+    p, _ = su.camera_params(cam, 1920, 1080)
+    out = torch.empty((1080, 1920, 3), dtype=torch.float32, device="cuda")
+    for _ in range(3):
+        abi.check(lib.nrays_render_device(sc.device_handle(), C.byref(p), C.c_void_p(out.data_ptr()), None))
+    cap = 1 << 20
+    buf = np.zeros(cap, np.uint32); n = C.c_uint32()
+    lib.nrays_debug_tile_costs.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+    abi.check(lib.nrays_debug_tile_costs(sc.device_handle(), buf.ctypes.data, cap, C.byref(n)))
+    c = np.sort(buf[:n.value].astype(np.float64) * 16)[::-1]
+    tot = c.sum()
+    res = {"scene": name, "wave_tiles": int(n.value), "total_wave_cycles": float(tot), "max_tile_cycles": float(c[0]), "median_tile_cycles": float(np.median(c))}
+    for q in (0.001, 0.01, 0.05, 0.10, 0.25, 0.5):
+        k = max(1, int(q * len(c)))
+        res["share_of_top_%g%%" % (q * 100)] = round(float(c[:k].sum() / tot), 3)
+    print(json.dumps(res), flush=True)
