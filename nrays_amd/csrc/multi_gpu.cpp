@@ -50,6 +50,13 @@ constexpr uint32_t kBandRows = 16; // one 16x16 workgroup tile high
             return nrays::set_last_error(NRAYS_ERR_RCCL, std::string(#expr) + ": " + ncclGetErrorString(r_));     \
     } while (0)
 
+// Restores the calling thread's current HIP device on every exit path (the entry points switch devices per owner).
+struct DeviceGuard {
+    int device = 0;
+    DeviceGuard() { (void)hipGetDevice(&device); }
+    ~DeviceGuard() { (void)hipSetDevice(device); }
+};
+
 } // namespace
 
 struct NraysComm {
@@ -183,9 +190,8 @@ int nrays_scene_set_create(const NraysSceneDesc* desc, NraysComm* comm, NraysSce
     *out_set = nullptr;
     NraysSceneSet* s = new NraysSceneSet();
     s->comm = comm;
-    int restore = 0;
-    (void)hipGetDevice(&restore);
-    auto bail = [&](int rc) { nrays_scene_set_destroy(s); (void)hipSetDevice(restore); return rc; };
+    DeviceGuard guard;
+    auto bail = [&](int rc) { nrays_scene_set_destroy(s); return rc; };
     const uint32_t first = comm->ranked ? comm->rank : 0u, count = comm->ranked ? 1u : comm->owners;
     for (uint32_t k = 0; k < count; ++k) {
         NraysSceneSet::Owner o;
@@ -201,7 +207,6 @@ int nrays_scene_set_create(const NraysSceneDesc* desc, NraysComm* comm, NraysSce
                 hipEventCreateWithFlags(&o.sent[b], hipEventDisableTiming) != hipSuccess) { s->local.push_back(o); return bail(nrays::set_last_error(NRAYS_ERR_HIP, "event creation failed")); }
         s->local.push_back(o);
     }
-    (void)hipSetDevice(restore);
     *out_set = s;
     return NRAYS_OK;
 }
@@ -251,8 +256,7 @@ int nrays_render_multi_device(NraysSceneSet* s, const NraysRenderParams* params,
     if (params->width == 0 || params->height == 0 || params->ray_per_pixel == 0) return nrays::set_last_error(NRAYS_ERR_BAD_ARG, "bad render parameters");
     NraysComm* c = s->comm;
     const uint32_t owners = c->owners;
-    int restore = 0;
-    (void)hipGetDevice(&restore);
+    DeviceGuard guard;
     int rc = ensure_buffers(s, params);
     if (rc != NRAYS_OK) return rc;
     const int slot = (int)(s->step & 1u);
@@ -266,7 +270,7 @@ int nrays_render_multi_device(NraysSceneSet* s, const NraysRenderParams* params,
         if (s->step >= 2) MG_HIP(hipStreamWaitEvent(o.render_stream, o.sent[slot], 0)); // tile[slot] of frame k - 2 has left
         float* dst = (owners == 1) ? out_rgb_device : o.tile[slot];
         rc = nrays_render_device(o.scene, &q, dst, (void*)o.render_stream);
-        if (rc != NRAYS_OK) { (void)hipSetDevice(restore); return rc; }
+        if (rc != NRAYS_OK) return rc;
         MG_HIP(hipEventRecord(o.rendered[slot], o.render_stream));
         MG_HIP(hipStreamWaitEvent(o.comm_stream, o.rendered[slot], 0));
     }
@@ -321,25 +325,22 @@ int nrays_render_multi_device(NraysSceneSet* s, const NraysRenderParams* params,
         if (root) {
             MG_HIP(hipSetDevice(root->device));
             rc = nrays_untile_device(s->gathered[slot], out_rgb_device, params->width, params->height, kBandRows, owners, (void*)root->comm_stream);
-            if (rc != NRAYS_OK) { (void)hipSetDevice(restore); return rc; }
+            if (rc != NRAYS_OK) return rc;
         }
     }
     s->width = params->width; s->height = params->height;
     s->step++;
-    (void)hipSetDevice(restore);
     return NRAYS_OK;
 }
 
 int nrays_multi_sync(NraysSceneSet* s) {
     if (!s) return nrays::set_last_error(NRAYS_ERR_BAD_ARG, "null argument");
-    int restore = 0;
-    (void)hipGetDevice(&restore);
+    DeviceGuard guard;
     for (auto& o : s->local) {
         MG_HIP(hipSetDevice(o.device));
         MG_HIP(hipStreamSynchronize(o.render_stream));
         MG_HIP(hipStreamSynchronize(o.comm_stream));
     }
-    (void)hipSetDevice(restore);
     return NRAYS_OK;
 }
 
@@ -351,27 +352,23 @@ int nrays_render_multi(NraysSceneSet* s, const NraysRenderParams* params, float*
     if (s->has_root()) {
         if (!out_rgb) return nrays::set_last_error(NRAYS_ERR_BAD_ARG, "owner 0 needs an output buffer");
         const size_t floats = (size_t)params->width * params->height * 3;
-        int restore = 0;
-        (void)hipGetDevice(&restore);
+        DeviceGuard guard;
         MG_HIP(hipSetDevice(s->local[0].device));
         if (floats > s->frame_floats) {
             if (s->frame) { (void)hipFree(s->frame); s->frame = nullptr; s->frame_floats = 0; }
             MG_HIP(hipMalloc((void**)&s->frame, floats * sizeof(float)));
             s->frame_floats = floats;
         }
-        (void)hipSetDevice(restore);
         dev_out = s->frame;
     }
     int rc = nrays_render_multi_device(s, params, dev_out);
     if (rc != NRAYS_OK) return rc;
     if (s->has_root()) {
         NraysSceneSet::Owner& root = s->local[0];
-        int restore = 0;
-        (void)hipGetDevice(&restore);
+        DeviceGuard guard;
         MG_HIP(hipSetDevice(root.device));
         hipStream_t last = s->comm->owners > 1 ? root.comm_stream : root.render_stream;
         MG_HIP(hipMemcpyAsync(out_rgb, s->frame, (size_t)params->width * params->height * 3 * sizeof(float), hipMemcpyDeviceToHost, last));
-        (void)hipSetDevice(restore);
     }
     return nrays_multi_sync(s);
 }
@@ -381,20 +378,18 @@ int nrays_render_multi(NraysSceneSet* s, const NraysRenderParams* params, float*
 int nrays_multi_get_stats(NraysSceneSet* s, NraysStats* out) {
     if (!s || !out) return nrays::set_last_error(NRAYS_ERR_BAD_ARG, "null argument");
     std::memset(out, 0, sizeof *out);
-    int restore = 0;
-    (void)hipGetDevice(&restore);
+    DeviceGuard guard;
     for (size_t k = 0; k < s->local.size(); ++k) {
         NraysStats st;
         (void)hipSetDevice(s->local[k].device);
         int rc = nrays_get_stats(s->local[k].scene, &st);
-        if (rc != NRAYS_OK) { (void)hipSetDevice(restore); return rc; }
+        if (rc != NRAYS_OK) return rc;
         out->rays_primary += st.rays_primary; out->rays_reflection += st.rays_reflection; out->rays_refraction += st.rays_refraction;
         out->rays_shadow += st.rays_shadow; out->node_tests += st.node_tests; out->tri_tests += st.tri_tests; out->prim_tests += st.prim_tests;
         out->hit_records += st.hit_records; out->tex_samples += st.tex_samples;
         out->generations = std::max(out->generations, st.generations);
         if (k == 0) { out->kernel_ms_primary = st.kernel_ms_primary; out->kernel_ms_total = st.kernel_ms_total; out->frames_timed = st.frames_timed; out->instrumented = st.instrumented; }
     }
-    (void)hipSetDevice(restore);
     return NRAYS_OK;
 }
 
