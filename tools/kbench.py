@@ -64,7 +64,7 @@ def run_one(scene_name, steps, width, height, check):
            "rays": st.total_rays(), "primary_ms": round(ts.kernel_ms_primary, 4), "gpu_ms": round(ts.kernel_ms_total, 4),
            "node_per_ray": round(st.node_tests / st.total_rays(), 1), "tri_per_ray": round(st.tri_tests / st.total_rays(), 2),
            "gens": st.generations, "build_s": round(t_build, 2),
-           "GBs_alg": round(st.algorithmic_bytes(width, height) / (ts.kernel_ms_total * 1e-3) / 1e9, 1)}
+           "GBs_alg": round(st.algorithmic_bytes(width, height) / (ts.kernel_ms_total * 1e-3) / 1e9, 1) if ts.kernel_ms_total > 0 else None}
     if check:
         import oracle
         cw, ch = 160, 90
