@@ -228,7 +228,9 @@ __global__ void __launch_bounds__(kBlock, waves_per_simd(FEAT)) k_primary(DScene
             const uint32_t s = g + q;
             const bool sample_active = active && s < s_end;
             RayState ray;
-            generate_primary<PLAIN>(R, i, j, s, pix, ray);
+            // lanes outside the frame (ragged right edge, padding rows of a band) still execute the ray generation: keep their
+            // table reads inside the tables
+            generate_primary<PLAIN>(R, i < R.width ? i : R.width - 1u, j < R.height ? j : R.height - 1u, s, pix, ray);
             unsigned node_before = cnt.node;
             f3 c;
             if (__ballot(sample_active && primary_may_hit(S, ray.o, ray.d)) == 0ULL) {

@@ -542,17 +542,22 @@ struct Hit {
 //                          RELATIVE to t (3 * 2^-24, + 2^-24 for the fma's own rounding -> relative slack 2^-21 = 4.8e-7
 //                          on the final compare), while the roundings of o32 and of n are absolute, 2 * 2^-24 |o inv|
 //                          together -> absolute margin e = |o32 * inv32| 2^-22 per axis (twice that)
-// A zero direction component uses the finite inverse 1e30 (no NaN from 0 * inf; the margin then
-// decides inside/outside of the slab conservatively).
+// A direction component that is zero in f32 (|d| below ~1e-30) is taken out of the slab arithmetic: inverse 0, offset 0 and
+// an infinite margin make that axis' interval (-inf, +inf), and zero_axis_cull() applies the reference's rule for a zero
+// component — the ray misses iff its origin lies outside [mn, mx] — with the rounding of the origin as margin.  (Round 1 used the finite inverse 1e30 and let the margin decide;
+// but the margin |o inv| 2^-22 is ZERO for an origin coordinate of exactly 0, and a box with a face exactly in that
+// coordinate plane — mx == o — then gets the interval [-huge, 0] and is culled, while the reference's test for a zero
+// component, `o < mn || o > mx`, accepts the boundary.  Found by the full-size 3840x2160 comparison with the oracle: two
+// pixels of the centre column, whose rays lie exactly in the stand-in's symmetry plane z = 0.)
 struct RayF {
     float nx, ny, nz; // -(o32 * inv32): the slab distances are ONE fused multiply-add per plane, fma(b, inv32, n)
     float ix, iy, iz, ex, ey, ez;
+    uint32_t zero_axes; // bit a: the direction's component a is zero in f32 (the slab arithmetic leaves that axis unconstrained; zero_axis_cull() handles it)
 };
-NR_DEV float inv_f32(double d) {
+NR_DEV float inv_f32(double d) { // 0 = "this axis does not constrain the ray" (see above)
     float x = (float)d;
-    float r = x == 0.0f ? 1e30f : __builtin_amdgcn_rcpf(x);
-    if (!(fabsf(r) < 1e30f)) r = copysignf(1e30f, r);
-    return r;
+    float r = __builtin_amdgcn_rcpf(x);
+    return (fabsf(x) > 1e-30f && fabsf(r) < 1e30f) ? r : 0.0f;
 }
 NR_DEV RayF make_rayf(d3 o, d3 d) {
     RayF r;
@@ -560,9 +565,11 @@ NR_DEV RayF make_rayf(d3 o, d3 d) {
     r.ix = inv_f32(d.x); r.iy = inv_f32(d.y); r.iz = inv_f32(d.z);
     const float px = ox * r.ix, py = oy * r.iy, pz = oz * r.iz;
     r.nx = -px; r.ny = -py; r.nz = -pz;
-    r.ex = fabsf(px) * 2.384185791015625e-07f; // 2^-22
-    r.ey = fabsf(py) * 2.384185791015625e-07f;
-    r.ez = fabsf(pz) * 2.384185791015625e-07f;
+    const float kInf = __builtin_inff();
+    r.ex = r.ix != 0.0f ? fabsf(px) * 2.384185791015625e-07f : kInf; // 2^-22; unconstrained axis: infinite margin
+    r.ey = r.iy != 0.0f ? fabsf(py) * 2.384185791015625e-07f : kInf;
+    r.ez = r.iz != 0.0f ? fabsf(pz) * 2.384185791015625e-07f : kInf;
+    r.zero_axes = (r.ix == 0.0f ? 1u : 0u) | (r.iy == 0.0f ? 2u : 0u) | (r.iz == 0.0f ? 4u : 0u);
     return r;
 }
 // Upper f32 bound of the current best distance (ties with it must still be visited).
@@ -608,6 +615,26 @@ NR_DEV void box_entry4(float4 mnx, float4 mny, float4 mnz, float4 mxx, float4 mx
     t3 = (n3 * 0.9999995f <= f3 * 1.0000005f) ? n3 : -1.0f;
 }
 
+// The axes box_entry4 left unconstrained (RayF::zero_axes, rays exactly parallel to a coordinate plane — rare, but a
+// camera on a symmetry plane of the scene produces a whole column of them): ncollide's ray_aabb rejects such a ray iff its
+// origin coordinate lies outside [mn, mx] (SURVEY B-3).  o32 = fl(o) is off by at most 2^-24 |o| and the f32 bounds
+// contain the f64 ones, so "o32 + m < mn or o32 - m > mx" with m = 2^-22 |o32| + 1e-20 implies the reference's rejection.
+// (The 1e-20 covers components that are not exactly zero but below 1e-30, which the f32 view also treats as zero: the
+// reference would divide by them, and an origin less than 1e-20 outside the slab could still reach it within 1e10 units.)
+NR_DEV void zero_axis_cull(uint32_t zero_axes, d3 o, float4 mnx, float4 mny, float4 mnz, float4 mxx, float4 mxy, float4 mxz,
+                           float& t0, float& t1, float& t2, float& t3) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        if (!(zero_axes & (1u << a))) continue;
+        const float o32 = (float)comp(o, a), m = fabsf(o32) * 2.384185791015625e-07f + 1e-20f;
+        const float4 mn = a == 0 ? mnx : (a == 1 ? mny : mnz), mx = a == 0 ? mxx : (a == 1 ? mxy : mxz);
+        if (o32 + m < mn.x || o32 - m > mx.x) t0 = -1.0f;
+        if (o32 + m < mn.y || o32 - m > mx.y) t1 = -1.0f;
+        if (o32 + m < mn.z || o32 - m > mx.z) t2 = -1.0f;
+        if (o32 + m < mn.w || o32 - m > mx.w) t3 = -1.0f;
+    }
+}
+
 // Whether a primary ray can reach anything at all: exactly the first step of traverse<false> (same f32
 // ray view, same root fetch, same conservative box test), so "false" means that traversal would return
 // a miss and Scene::trace the background colour.  k_primary uses it to let wave tiles of empty screen
@@ -623,6 +650,7 @@ NR_DEV bool primary_may_hit(const DScene& S, d3 o, d3 d) {
     int4 ch = ((const int4*)q)[6];
     float t0, t1, t2, t3;
     box_entry4(mnx, mny, mnz, mxx, mxy, mxz, rf, best_f32(kDblMax), t0, t1, t2, t3);
+    if (rf.zero_axes) zero_axis_cull(rf.zero_axes, o, mnx, mny, mnz, mxx, mxy, mxz, t0, t1, t2, t3);
     return (t0 >= 0.0f && ch.x != kEmptyChild) || (t1 >= 0.0f && ch.y != kEmptyChild) ||
            (t2 >= 0.0f && ch.z != kEmptyChild) || (t3 >= 0.0f && ch.w != kEmptyChild);
 }
@@ -774,6 +802,7 @@ NR_DEV bool traverse(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, Hit&
             if (STATS) cnt.node += (unsigned)(ch.x != kEmptyChild) + (unsigned)(ch.y != kEmptyChild) + (unsigned)(ch.z != kEmptyChild) + (unsigned)(ch.w != kEmptyChild);
             float t0, t1, t2, t3;
             box_entry4(mnx, mny, mnz, mxx, mxy, mxz, rf, btf, t0, t1, t2, t3);
+            if (rf.zero_axes) zero_axis_cull(rf.zero_axes, co, mnx, mny, mnz, mxx, mxy, mxz, t0, t1, t2, t3);
             // misses (and absent children, whose inverted boxes always miss) sort last with key +inf
             const float kMiss = __builtin_inff();
             float k0 = (t0 >= 0.0f && ch.x != kEmptyChild) ? t0 : kMiss, k1 = (t1 >= 0.0f && ch.y != kEmptyChild) ? t1 : kMiss;
