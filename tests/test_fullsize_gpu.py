@@ -63,3 +63,26 @@ def test_config4_sponza_standin_8_lights_full_4k(gpu):
     p, _ = su.camera_params(cam, 3840, 2160)
     err, st = _full_frame(sc, p)
     assert st.rays_primary == 3840 * 2160 and st.rays_shadow >= 8 * 0.9 * 3840 * 2160
+
+
+def test_hairball_standin_full_1080p_and_aa(gpu):
+    """The 2.88 M-triangle stand-in at 1920x1080: one sample per pixel, then `aa 4 1.0` (sample-major lane mapping, 4 lanes
+    per pixel) — every pixel against the oracle."""
+    sc, cam = standins.hairball_scene()
+    p, _ = su.camera_params(cam, 1920, 1080)
+    _full_frame(sc, p)
+    p4, _ = su.camera_params(cam, 960, 540, spp=4, window=1.0, seed=1)
+    _, st = _full_frame(sc, p4)
+    assert st.rays_primary == 960 * 540 * 4
+
+
+def test_primitives_scene_file_full_1080p_area_light(gpu):
+    """BASELINE config 1's file as shipped (area light: 9 jittered shadow rays per hit, transparent shapes, reflecting
+    plane) at 1920x1080 with the counter-based RNG."""
+    from tools import gen_assets
+    gen_assets.gen_globe()
+    fs = scenefile.FileScene(os.path.join(ROOT, "scenes", "primitives.scene"))
+    cam = fs.camera_dict()
+    p = nr.make_params((1920, 1080), 1, 0.0, cam["eye"], fs.inverse_projection(0, 1920, 1080), seed=5)
+    _, st = _full_frame(fs, p)
+    assert st.rays_shadow > 9 * 0.3 * 1920 * 1080

@@ -361,3 +361,33 @@ def test_long_thin_diagonal_triangles(gpu):
     _, _, st, _ = compare(sc, cam, 400, 300)
     assert st.rays_shadow > 0 and st.rays_reflection > 0
     compare(sc, dict(cam, eye=(-9.0, -3.0, 6.0)), 233, 171)
+
+
+def test_rays_in_a_coordinate_plane_with_box_faces_in_that_plane(gpu):
+    """Regression for the round-2 culling fix: a fan of triangles around the camera axis has vertices exactly in
+    the planes x = 0 and y = 0, so many leaf boxes have a FACE in those planes, and with an even resolution the centre
+    column / row of pixels have rays with d.x == 0 / d.y == 0 exactly and an origin coordinate of exactly 0 — the case in
+    which a zero margin used to cull boxes the reference's `o < mn || o > mx` rule accepts.  Every pixel against the
+    oracle, for an identity and a translated node (the translated one moves the planes off the f32 grid's zero)."""
+    n = 48
+    ang = np.arange(n) * (2 * np.pi / n)
+    ring = np.stack([2.0 * np.cos(ang), 2.0 * np.sin(ang), np.full(n, 8.0)], 1)
+    ring[np.abs(ring) < 1e-12] = 0.0  # the four axis points exactly on x = 0 / y = 0
+    pts = su.f32_exact(np.concatenate([[[0.0, 0.0, 5.0]], ring, [[0.0, 0.0, 8.0]]]))
+    tris = []
+    for k in range(n):
+        a, b = 1 + k, 1 + (k + 1) % n
+        tris.append([0, a, b])          # cone side: apex on the camera axis
+        tris.append([n + 1, b, a])      # base disc: centre on the camera axis
+    idx = np.array(tris, dtype=np.uint32)
+    uvs = su.f32_exact(np.random.default_rng(5).uniform(0, 1, (len(pts), 2)))
+    mat = nr.PhongMaterial((0.2, 0.2, 0.2), (0.8, 0.7, 0.6), (1, 1, 1), su.checker_texture(32, 4), None, 30.0)
+    for trans in [(0.0, 0.0, 0.0), (0.0, 0.0, 1.5)]:
+        node = nr.SceneNode(mat, 0.3, 0.5, 1.0, 1.0, nr.Isometry3(trans), nr.TriMesh(pts, idx, uvs))
+        floor = nr.SceneNode(su.default_material(), 0.0, 0.0, 1.0, 1.0, nr.Isometry3((0.0, 0.0, 0.0)),
+                             nr.TriMesh(su.f32_exact([[-6, -6, 12], [6, -6, 12], [6, 6, 12], [-6, 6, 12], [0, 0, 12]]),
+                                        np.array([[0, 1, 4], [1, 2, 4], [2, 3, 4], [3, 0, 4]], dtype=np.uint32), None))
+        sc = nr.Scene([node, floor], [nr.Light((0.0, 0.0, -5.0), 0.0, 1, (1, 1, 1)), nr.Light((3.0, 4.0, 0.0), 0.0, 1, (0.5, 0.5, 0.5))], (0.1, 0.2, 0.3))
+        cam = dict(eye=(0.0, 0.0, -5.0), at=(0.0, 0.0, 0.0), fovy=50.0)
+        compare(sc, cam, 256, 192)   # centre column i = 128: d.x == 0; centre row j = 96: d.y == 0
+        compare(sc, cam, 64, 64)
