@@ -203,13 +203,15 @@ struct Collapser {
         BvhNode& n = out[me];
         for (int k = 0; k < 4; ++k) {
             if (k < (int)slots.size()) {
-                for (int a = 0; a < 3; ++a) { n.mn[a][k] = slots[k].mn[a]; n.mx[a][k] = slots[k].mx[a]; }
-                n.child[k] = refs[k];
-            } else {
-                for (int a = 0; a < 3; ++a) { n.mn[a][k] = std::numeric_limits<float>::infinity(); n.mx[a][k] = -std::numeric_limits<float>::infinity(); }
-                n.child[k] = kEmptyChild;
+                n.set_box(k, slots[k].mn, slots[k].mx);
+                n.children()[k] = refs[k];
+            } else { // finite (a zero inverse direction times infinity would be a NaN) and inverted: no ray enters it
+                const float big = std::numeric_limits<float>::max();
+                const float mn[3] = {big, big, big}, mx[3] = {-big, -big, -big};
+                n.set_box(k, mn, mx);
+                n.children()[k] = kEmptyChild;
             }
-            n.pad[k] = 0;
+            n.slot[5][k] = 0.0f;
         }
         return me;
     }
@@ -238,7 +240,7 @@ BuiltBvh build_bvh(const std::vector<PrimBounds>& prims, int max_leaf) {
 
 void rebase_bvh(BuiltBvh& bvh, int32_t node_base, uint32_t prim_base) {
     for (BvhNode& n : bvh.nodes)
-        for (int k = 0; k < 4; ++k) n.child[k] = rebase_ref(n.child[k], node_base, prim_base);
+        for (int k = 0; k < 4; ++k) n.children()[k] = rebase_ref(n.children()[k], node_base, prim_base);
     bvh.root = rebase_ref(bvh.root, node_base, prim_base);
 }
 

@@ -14,12 +14,19 @@ namespace nrays {
 // AABB::toi_with_ray, src/scene.rs:276).
 // child >= 0: index of an internal node; child < 0: leaf, ~child = (first << 3) | bits, where bits =
 // count - 1 for triangle leaves (BLAS) and LeafBits for TLAS leaves (first = instance index).  An
-// absent child has an inverted box (min = +inf, max = -inf) and child = kEmptyChild.
+// absent child has an inverted box (min = +FLT_MAX, max = -FLT_MAX: finite, so that a zero inverse
+// direction cannot turn it into a NaN) that no ray can enter, and child = kEmptyChild.
 struct BvhNode {
-    float mn[3][4]; // mn[axis][child]: one dwordx4 = the same coordinate of all four children, so the
-    float mx[3][4]; // slab arithmetic runs two children per packed-f32 instruction (v_pk_add/mul_f32)
-    int32_t child[4];
-    uint32_t pad[4];
+    // Eight 16-byte slots.  One slot = the same plane of all four children (the slab arithmetic runs two children per
+    // packed-f32 instruction).  The lower and upper plane of an axis sit at byte offsets that differ in ONE address bit —
+    // x: 0 / 16, y: 64 / 96, z: 48 / 112 — so a lane fetches the plane its ray ENTERS through at
+    // `lower offset | (direction negative ? that bit : 0)` and the exit plane at that address ^ bit: the near / far
+    // selection of the slab test costs no instruction (trace_device.h: load_planes).  Children at 32, slot 80 unused.
+    float slot[8][4];
+    static constexpr int kLoSlot[3] = {0, 4, 3}, kHiSlot[3] = {1, 6, 7}, kChildSlot = 2;
+    void set_box(int k, const float mn[3], const float mx[3]) { for (int a = 0; a < 3; ++a) { slot[kLoSlot[a]][k] = mn[a]; slot[kHiSlot[a]][k] = mx[a]; } }
+    int32_t* children() { return reinterpret_cast<int32_t*>(slot[kChildSlot]); }
+    const int32_t* children() const { return reinterpret_cast<const int32_t*>(slot[kChildSlot]); }
 };
 static_assert(sizeof(BvhNode) == 128, "BvhNode must be 128 bytes");
 constexpr int32_t kEmptyChild = (int32_t)0x80000000;

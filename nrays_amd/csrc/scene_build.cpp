@@ -408,7 +408,7 @@ int32_t append_tlas(std::vector<Instance>& insts, const std::vector<PrimBounds>&
                         ((in.kind == NRAYS_SHAPE_TRIMESH && (in.flags & kInstNoXform)) ? kLeafNoXform : 0u);
         return ~(int32_t)((first << 3) | bits);
     };
-    for (BvhNode& n : bvh.nodes) for (int k = 0; k < 4; ++k) n.child[k] = tag(n.child[k]);
+    for (BvhNode& n : bvh.nodes) for (int k = 0; k < 4; ++k) n.children()[k] = tag(n.children()[k]);
     bvh.root = tag(bvh.root);
     out.max_bvh_depth = std::max(out.max_bvh_depth, bvh.max_depth);
     out.nodes.insert(out.nodes.end(), bvh.nodes.begin(), bvh.nodes.end());
@@ -620,6 +620,8 @@ int build_host_scene(const NraysSceneDesc* d, HostScene& out, std::string& err) 
     out.shadow_instances.swap(sinst);
     for (const Instance& in : out.instances) out.links.push_back(InstLink{in.blas_root, in.flags});
     for (const Instance& in : out.shadow_instances) out.shadow_links.push_back(InstLink{in.blas_root, in.flags});
+    // the traversal addresses a node as base + 32-bit byte offset (trace_device.h: load_planes)
+    if (out.nodes.size() >= ((size_t)1 << 25)) { err = "scene too large: more than 2^25 BVH nodes"; return NRAYS_ERR_BAD_ARG; }
     return NRAYS_OK;
 }
 

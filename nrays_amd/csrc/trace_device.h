@@ -535,24 +535,33 @@ struct Hit {
 // f32 view of a ray for box culling.  The BVH bounds are exact f32 supersets of the f64 geometry; the
 // slab test runs in f32 with explicit error margins so that it is a SUPERSET of the f64 slab test
 // (ncollide ray_aabb, called at src/scene.rs:276) and can therefore never change a result:
-//   o32 = fl(o)            |o - o32| <= |o| 2^-24
-//   inv32 = rcp(fl(d))     relative error <= 2^-24 (rounding of d) + 2^-23 (v_rcp_f32, 1 ulp)
-//   n = -fl(o32 * inv32)   one more rounding of |o inv|
-//   t = fma(b, inv32, n)   = fl((b - o32) inv32 + rounding of n): b inv32 and o32 inv32 share inv32, so its error stays
-//                          RELATIVE to t (3 * 2^-24, + 2^-24 for the fma's own rounding -> relative slack 2^-21 = 4.8e-7
-//                          on the final compare), while the roundings of o32 and of n are absolute, 2 * 2^-24 |o inv|
-//                          together -> absolute margin e = |o32 * inv32| 2^-22 per axis (twice that)
-// A direction component that is zero in f32 (|d| below ~1e-30) is taken out of the slab arithmetic: inverse 0, offset 0 and
-// an infinite margin make that axis' interval (-inf, +inf), and zero_axis_cull() applies the reference's rule for a zero
-// component — the ray misses iff its origin lies outside [mn, mx] — with the rounding of the origin as margin.  (Round 1 used the finite inverse 1e30 and let the margin decide;
-// but the margin |o inv| 2^-22 is ZERO for an origin coordinate of exactly 0, and a box with a face exactly in that
+//   o32 = fl(o)              |o - o32| <= |o| 2^-24
+//   inv32 = rcp(fl(d))       relative error <= 2^-24 (rounding of d) + 2^-23 (v_rcp_f32, 1 ulp)
+//   p = fl(o32 * inv32)      one more rounding of |o inv|
+//   e = |p| 2^-21            the absolute margin of the axis
+//   n_near = fl(-p - e),  n_far = fl(-p + e)      (a third rounding of magnitude 2^-24 |p|)
+//   t_near = fma(b_near, inv32, n_near),  t_far = fma(b_far, inv32, n_far)
+// b inv32 and o32 inv32 share inv32, so its error stays RELATIVE to t (3 * 2^-24, + 2^-24 for the fma's own rounding ->
+// relative slack on the final compare), while the roundings of o32, of p and of n_near / n_far are absolute, at most
+// 3 * 2^-24 |o inv| together, well inside e = 8 * 2^-24 |p|.  The margin is part of the fma's addend, so a slab costs one
+// instruction per plane.  b_near is the plane the ray enters through — the lower bound for a positive direction
+// component, the upper one for a negative one — and the lane FETCHES it from there (BvhNode keeps the two planes of an
+// axis one address bit apart and RayF::bits holds those bits), so no min / max separates near from far.
+// A direction component that is zero in f32 (|d| below ~1e-30) is taken out of the slab arithmetic: inverse 0 and the
+// addends -inf / +inf make that axis' interval (-inf, +inf) (the bounds are finite, so no NaN can arise), and
+// zero_axis_cull() applies the reference's rule for a zero component — the ray misses iff its origin lies outside
+// [mn, mx] — with the rounding of the origin as margin.  (Round 1 used the finite inverse 1e30 and let the margin
+// decide; but the margin is ZERO for an origin coordinate of exactly 0, and a box with a face exactly in that
 // coordinate plane — mx == o — then gets the interval [-huge, 0] and is culled, while the reference's test for a zero
 // component, `o < mn || o > mx`, accepts the boundary.  Found by the full-size 3840x2160 comparison with the oracle: two
 // pixels of the centre column, whose rays lie exactly in the stand-in's symmetry plane z = 0.)
 struct RayF {
-    float nx, ny, nz; // -(o32 * inv32): the slab distances are ONE fused multiply-add per plane, fma(b, inv32, n)
-    float ix, iy, iz, ex, ey, ez;
-    uint32_t zero_axes; // bit a: the direction's component a is zero in f32 (the slab arithmetic leaves that axis unconstrained; zero_axis_cull() handles it)
+    float ix, iy, iz;       // inv32 per axis
+    float nnx, nny, nnz;    // n_near
+    float nfx, nfy, nfz;    // n_far
+    uint32_t bits;          // bits 4 / 5 / 6: direction component x / y / z negative (= the address bit that selects the
+                            // upper plane of that axis inside a BvhNode); bits 0..2: component a is zero in f32
+                            // (zero_axis_cull() handles that axis)
 };
 NR_DEV float inv_f32(double d) { // 0 = "this axis does not constrain the ray" (see above)
     float x = (float)d;
@@ -564,74 +573,75 @@ NR_DEV RayF make_rayf(d3 o, d3 d) {
     const float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z;
     r.ix = inv_f32(d.x); r.iy = inv_f32(d.y); r.iz = inv_f32(d.z);
     const float px = ox * r.ix, py = oy * r.iy, pz = oz * r.iz;
-    r.nx = -px; r.ny = -py; r.nz = -pz;
-    const float kInf = __builtin_inff();
-    r.ex = r.ix != 0.0f ? fabsf(px) * 2.384185791015625e-07f : kInf; // 2^-22; unconstrained axis: infinite margin
-    r.ey = r.iy != 0.0f ? fabsf(py) * 2.384185791015625e-07f : kInf;
-    r.ez = r.iz != 0.0f ? fabsf(pz) * 2.384185791015625e-07f : kInf;
-    r.zero_axes = (r.ix == 0.0f ? 1u : 0u) | (r.iy == 0.0f ? 2u : 0u) | (r.iz == 0.0f ? 4u : 0u);
+    const float kInf = __builtin_inff(), k21 = 4.76837158203125e-07f; // 2^-21
+    const float ex = fabsf(px) * k21, ey = fabsf(py) * k21, ez = fabsf(pz) * k21;
+    r.nnx = r.ix != 0.0f ? -px - ex : -kInf; r.nfx = r.ix != 0.0f ? -px + ex : kInf;
+    r.nny = r.iy != 0.0f ? -py - ey : -kInf; r.nfy = r.iy != 0.0f ? -py + ey : kInf;
+    r.nnz = r.iz != 0.0f ? -pz - ez : -kInf; r.nfz = r.iz != 0.0f ? -pz + ez : kInf;
+    r.bits = (r.ix < 0.0f ? 16u : 0u) | (r.iy < 0.0f ? 32u : 0u) | (r.iz < 0.0f ? 64u : 0u) |
+             (r.ix == 0.0f ? 1u : 0u) | (r.iy == 0.0f ? 2u : 0u) | (r.iz == 0.0f ? 4u : 0u);
     return r;
 }
 // Upper f32 bound of the current best distance (ties with it must still be visited).
 NR_DEV float best_f32(double bt) { return (float)bt * 1.0000004f + 1e-37f; }
 
-// Returns the (approximate) entry distance, or -1 on a miss.
-NR_DEV float box_entry(float mnx, float mny, float mnz, float mxx, float mxy, float mxz, const RayF& r, float tbest) {
-    float x1 = __builtin_fmaf(mnx, r.ix, r.nx), x2 = __builtin_fmaf(mxx, r.ix, r.nx);
-    float y1 = __builtin_fmaf(mny, r.iy, r.ny), y2 = __builtin_fmaf(mxy, r.iy, r.ny);
-    float z1 = __builtin_fmaf(mnz, r.iz, r.nz), z2 = __builtin_fmaf(mxz, r.iz, r.nz);
-    float xn = fminf(x1, x2) - r.ex, xf = fmaxf(x1, x2) + r.ex;
-    float yn = fminf(y1, y2) - r.ey, yf = fmaxf(y1, y2) + r.ey;
-    float zn = fminf(z1, z2) - r.ez, zf = fmaxf(z1, z2) + r.ez;
-    float tn = fmaxf(fmaxf(xn, yn), fmaxf(zn, 0.0f));
-    float tf = fminf(fminf(xf, yf), fminf(zf, tbest));
-    return (tn * 0.9999995f <= tf * 1.0000005f) ? tn : -1.0f;
+// The six planes of the four children of node `node`, entry / exit plane per axis as the ray's signs select them.
+// The node array is addressed as uniform base + 32-bit byte offset (scene_build.cpp refuses scenes beyond 2^25 nodes).
+struct NodePlanes { float4 xn, xf, yn, yf, zn, zf; };
+NR_DEV NodePlanes load_planes(const BvhNode* nodes, int32_t node, const RayF& r) {
+    const char* base = (const char*)nodes;
+    const uint32_t at = (uint32_t)node << 7;
+    const uint32_t ax = at | (r.bits & 16u), ay = at | (r.bits & 32u), az = at | (r.bits & 64u); // v_and_or_b32
+    NodePlanes p;
+    p.xn = *(const float4*)(base + ax); p.xf = *(const float4*)(base + (ax ^ 16u));
+    p.yn = *(const float4*)(base + ay + 64); p.yf = *(const float4*)(base + (ay ^ 32u) + 64);
+    p.zn = *(const float4*)(base + az + 48); p.zf = *(const float4*)(base + (az ^ 64u) + 48);
+    return p;
 }
+NR_DEV int4 load_children(const BvhNode* nodes, int32_t node) { return *(const int4*)((const char*)nodes + (((uint32_t)node << 7) | 32u)); }
 
-// Four boxes at once (the SoA node layout of device_types.h): same arithmetic and margins as
-// box_entry, two children per packed-f32 instruction for the subtract / multiply / margin steps.
+// Four boxes at once: sort keys k = entry distance (>= 0) of a child the ray may enter before `tbest`, +inf for a child
+// it cannot (absent children hold an inverted box and always get +inf).  Two children per packed-f32 instruction.
 typedef float f2 __attribute__((ext_vector_type(2)));
-NR_DEV void slab2(f2 mn, f2 mx, float n, float inv, float e, f2& tn, f2& tf) {
-    f2 a = __builtin_elementwise_fma(mn, f2{inv, inv}, f2{n, n}), b = __builtin_elementwise_fma(mx, f2{inv, inv}, f2{n, n});
-    tn = __builtin_elementwise_min(a, b) - e;
-    tf = __builtin_elementwise_max(a, b) + e;
-}
-NR_DEV void box_entry4(float4 mnx, float4 mny, float4 mnz, float4 mxx, float4 mxy, float4 mxz, const RayF& r, float tbest,
-                       float& t0, float& t1, float& t2, float& t3) {
-    f2 xn0, xf0, xn1, xf1, yn0, yf0, yn1, yf1, zn0, zf0, zn1, zf1;
-    slab2(f2{mnx.x, mnx.y}, f2{mxx.x, mxx.y}, r.nx, r.ix, r.ex, xn0, xf0);
-    slab2(f2{mnx.z, mnx.w}, f2{mxx.z, mxx.w}, r.nx, r.ix, r.ex, xn1, xf1);
-    slab2(f2{mny.x, mny.y}, f2{mxy.x, mxy.y}, r.ny, r.iy, r.ey, yn0, yf0);
-    slab2(f2{mny.z, mny.w}, f2{mxy.z, mxy.w}, r.ny, r.iy, r.ey, yn1, yf1);
-    slab2(f2{mnz.x, mnz.y}, f2{mxz.x, mxz.y}, r.nz, r.iz, r.ez, zn0, zf0);
-    slab2(f2{mnz.z, mnz.w}, f2{mxz.z, mxz.w}, r.nz, r.iz, r.ez, zn1, zf1);
-    float n0 = fmaxf(fmaxf(xn0.x, yn0.x), fmaxf(zn0.x, 0.0f)), f0 = fminf(fminf(xf0.x, yf0.x), fminf(zf0.x, tbest));
-    float n1 = fmaxf(fmaxf(xn0.y, yn0.y), fmaxf(zn0.y, 0.0f)), f1 = fminf(fminf(xf0.y, yf0.y), fminf(zf0.y, tbest));
-    float n2 = fmaxf(fmaxf(xn1.x, yn1.x), fmaxf(zn1.x, 0.0f)), f2_ = fminf(fminf(xf1.x, yf1.x), fminf(zf1.x, tbest));
-    float n3 = fmaxf(fmaxf(xn1.y, yn1.y), fmaxf(zn1.y, 0.0f)), f3 = fminf(fminf(xf1.y, yf1.y), fminf(zf1.y, tbest));
-    t0 = (n0 * 0.9999995f <= f0 * 1.0000005f) ? n0 : -1.0f;
-    t1 = (n1 * 0.9999995f <= f1 * 1.0000005f) ? n1 : -1.0f;
-    t2 = (n2 * 0.9999995f <= f2_ * 1.0000005f) ? n2 : -1.0f;
-    t3 = (n3 * 0.9999995f <= f3 * 1.0000005f) ? n3 : -1.0f;
+NR_DEV void box_keys4(const NodePlanes& p, const RayF& r, float tbest, float& k0, float& k1, float& k2, float& k3) {
+    const f2 ix = {r.ix, r.ix}, iy = {r.iy, r.iy}, iz = {r.iz, r.iz};
+    const f2 nnx = {r.nnx, r.nnx}, nny = {r.nny, r.nny}, nnz = {r.nnz, r.nnz}, nfx = {r.nfx, r.nfx}, nfy = {r.nfy, r.nfy}, nfz = {r.nfz, r.nfz};
+    const f2 xn0 = __builtin_elementwise_fma(f2{p.xn.x, p.xn.y}, ix, nnx), xn1 = __builtin_elementwise_fma(f2{p.xn.z, p.xn.w}, ix, nnx);
+    const f2 xf0 = __builtin_elementwise_fma(f2{p.xf.x, p.xf.y}, ix, nfx), xf1 = __builtin_elementwise_fma(f2{p.xf.z, p.xf.w}, ix, nfx);
+    const f2 yn0 = __builtin_elementwise_fma(f2{p.yn.x, p.yn.y}, iy, nny), yn1 = __builtin_elementwise_fma(f2{p.yn.z, p.yn.w}, iy, nny);
+    const f2 yf0 = __builtin_elementwise_fma(f2{p.yf.x, p.yf.y}, iy, nfy), yf1 = __builtin_elementwise_fma(f2{p.yf.z, p.yf.w}, iy, nfy);
+    const f2 zn0 = __builtin_elementwise_fma(f2{p.zn.x, p.zn.y}, iz, nnz), zn1 = __builtin_elementwise_fma(f2{p.zn.z, p.zn.w}, iz, nnz);
+    const f2 zf0 = __builtin_elementwise_fma(f2{p.zf.x, p.zf.y}, iz, nfz), zf1 = __builtin_elementwise_fma(f2{p.zf.z, p.zf.w}, iz, nfz);
+    const float n0 = fmaxf(fmaxf(xn0.x, yn0.x), fmaxf(zn0.x, 0.0f)), f0 = fminf(fminf(xf0.x, yf0.x), fminf(zf0.x, tbest));
+    const float n1 = fmaxf(fmaxf(xn0.y, yn0.y), fmaxf(zn0.y, 0.0f)), f1 = fminf(fminf(xf0.y, yf0.y), fminf(zf0.y, tbest));
+    const float n2 = fmaxf(fmaxf(xn1.x, yn1.x), fmaxf(zn1.x, 0.0f)), f2_ = fminf(fminf(xf1.x, yf1.x), fminf(zf1.x, tbest));
+    const float n3 = fmaxf(fmaxf(xn1.y, yn1.y), fmaxf(zn1.y, 0.0f)), f3 = fminf(fminf(xf1.y, yf1.y), fminf(zf1.y, tbest));
+    // n <= f (1 + 1.4e-6): the relative slack of both distances on one side (n >= 0; a negative f never passes)
+    const float kMiss = __builtin_inff(), kSlack = 1.0000014f;
+    k0 = n0 <= f0 * kSlack ? n0 : kMiss;
+    k1 = n1 <= f1 * kSlack ? n1 : kMiss;
+    k2 = n2 <= f2_ * kSlack ? n2 : kMiss;
+    k3 = n3 <= f3 * kSlack ? n3 : kMiss;
 }
 
-// The axes box_entry4 left unconstrained (RayF::zero_axes, rays exactly parallel to a coordinate plane — rare, but a
+// The axes box_keys4 left unconstrained (the low bits of RayF::bits: rays exactly parallel to a coordinate plane — rare, but a
 // camera on a symmetry plane of the scene produces a whole column of them): ncollide's ray_aabb rejects such a ray iff its
 // origin coordinate lies outside [mn, mx] (SURVEY B-3).  o32 = fl(o) is off by at most 2^-24 |o| and the f32 bounds
 // contain the f64 ones, so "o32 + m < mn or o32 - m > mx" with m = 2^-22 |o32| + 1e-20 implies the reference's rejection.
 // (The 1e-20 covers components that are not exactly zero but below 1e-30, which the f32 view also treats as zero: the
 // reference would divide by them, and an origin less than 1e-20 outside the slab could still reach it within 1e10 units.)
-NR_DEV void zero_axis_cull(uint32_t zero_axes, d3 o, float4 mnx, float4 mny, float4 mnz, float4 mxx, float4 mxy, float4 mxz,
-                           float& t0, float& t1, float& t2, float& t3) {
+// For such an axis RayF::bits selects the lower bound as "entry" plane (inverse 0 is not negative).
+NR_DEV void zero_axis_cull(uint32_t zero_axes, d3 o, const NodePlanes& p, float& k0, float& k1, float& k2, float& k3) {
+    const float kMiss = __builtin_inff();
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         if (!(zero_axes & (1u << a))) continue;
         const float o32 = (float)comp(o, a), m = fabsf(o32) * 2.384185791015625e-07f + 1e-20f;
-        const float4 mn = a == 0 ? mnx : (a == 1 ? mny : mnz), mx = a == 0 ? mxx : (a == 1 ? mxy : mxz);
-        if (o32 + m < mn.x || o32 - m > mx.x) t0 = -1.0f;
-        if (o32 + m < mn.y || o32 - m > mx.y) t1 = -1.0f;
-        if (o32 + m < mn.z || o32 - m > mx.z) t2 = -1.0f;
-        if (o32 + m < mn.w || o32 - m > mx.w) t3 = -1.0f;
+        const float4 mn = a == 0 ? p.xn : (a == 1 ? p.yn : p.zn), mx = a == 0 ? p.xf : (a == 1 ? p.yf : p.zf);
+        if (o32 + m < mn.x || o32 - m > mx.x) k0 = kMiss;
+        if (o32 + m < mn.y || o32 - m > mx.y) k1 = kMiss;
+        if (o32 + m < mn.z || o32 - m > mx.z) k2 = kMiss;
+        if (o32 + m < mn.w || o32 - m > mx.w) k3 = kMiss;
     }
 }
 
@@ -645,20 +655,17 @@ NR_DEV bool primary_may_hit(const DScene& S, d3 o, d3 d) {
     if (cur == kEmptyChild) return false;
     if (cur < 0) return true; // single leaf: no box above it
     RayF rf = make_rayf(o, d);
-    const float4* q = (const float4*)(S.nodes + cur);
-    float4 mnx = q[0], mny = q[1], mnz = q[2], mxx = q[3], mxy = q[4], mxz = q[5];
-    int4 ch = ((const int4*)q)[6];
-    float t0, t1, t2, t3;
-    box_entry4(mnx, mny, mnz, mxx, mxy, mxz, rf, best_f32(kDblMax), t0, t1, t2, t3);
-    if (rf.zero_axes) zero_axis_cull(rf.zero_axes, o, mnx, mny, mnz, mxx, mxy, mxz, t0, t1, t2, t3);
-    return (t0 >= 0.0f && ch.x != kEmptyChild) || (t1 >= 0.0f && ch.y != kEmptyChild) ||
-           (t2 >= 0.0f && ch.z != kEmptyChild) || (t3 >= 0.0f && ch.w != kEmptyChild);
+    const NodePlanes p = load_planes(S.nodes, cur, rf);
+    float k0, k1, k2, k3;
+    box_keys4(p, rf, best_f32(kDblMax), k0, k1, k2, k3);
+    if ((rf.bits & 7u)) zero_axis_cull((rf.bits & 7u), o, p, k0, k1, k2, k3);
+    return fminf(fminf(k0, k1), fminf(k2, k3)) < __builtin_inff();
 }
 
 // Number of boxes the root node holds (instrumented builds: the AABB tests primary_may_hit stands for).
 NR_DEV unsigned root_children(const DScene& S) {
     if (S.closest_root < 0) return 0u;
-    int4 ch = ((const int4*)(S.nodes + S.closest_root))[6];
+    int4 ch = load_children(S.nodes, S.closest_root);
     return (unsigned)(ch.x != kEmptyChild) + (unsigned)(ch.y != kEmptyChild) + (unsigned)(ch.z != kEmptyChild) + (unsigned)(ch.w != kEmptyChild);
 }
 
@@ -793,20 +800,17 @@ NR_DEV bool traverse(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, Hit&
     for (;;) {
         NR_TOC(cyc_leaf, tphase);
         while (cur >= 0) {
-            const float4* q = (const float4*)(S.nodes + cur);
-            float4 mnx = q[0], mny = q[1], mnz = q[2], mxx = q[3], mxy = q[4], mxz = q[5];
-            int4 ch = ((const int4*)q)[6];
+            const NodePlanes np = load_planes(S.nodes, cur, rf);
+            const int4 ch = load_children(S.nodes, cur);
             NR_ITER(wv_node, ln_node);
             NR_UNIFORM(cur);
             // SURVEY 8d counts AABB tests: only the boxes that exist (an absent child slot is not a test)
             if (STATS) cnt.node += (unsigned)(ch.x != kEmptyChild) + (unsigned)(ch.y != kEmptyChild) + (unsigned)(ch.z != kEmptyChild) + (unsigned)(ch.w != kEmptyChild);
-            float t0, t1, t2, t3;
-            box_entry4(mnx, mny, mnz, mxx, mxy, mxz, rf, btf, t0, t1, t2, t3);
-            if (rf.zero_axes) zero_axis_cull(rf.zero_axes, co, mnx, mny, mnz, mxx, mxy, mxz, t0, t1, t2, t3);
-            // misses (and absent children, whose inverted boxes always miss) sort last with key +inf
+            // sort keys: entry distance, +inf for a child the ray cannot enter (absent children always: inverted boxes)
             const float kMiss = __builtin_inff();
-            float k0 = (t0 >= 0.0f && ch.x != kEmptyChild) ? t0 : kMiss, k1 = (t1 >= 0.0f && ch.y != kEmptyChild) ? t1 : kMiss;
-            float k2 = (t2 >= 0.0f && ch.z != kEmptyChild) ? t2 : kMiss, k3 = (t3 >= 0.0f && ch.w != kEmptyChild) ? t3 : kMiss;
+            float k0, k1, k2, k3;
+            box_keys4(np, rf, btf, k0, k1, k2, k3);
+            if ((rf.bits & 7u)) zero_axis_cull((rf.bits & 7u), co, np, k0, k1, k2, k3);
             int32_t c0 = ch.x, c1 = ch.y, c2 = ch.z, c3 = ch.w;
             if (!SHADOW) {
                 // closest hit: 5-comparator sorting network on (key, ref), ascending entry distance;
@@ -814,19 +818,38 @@ NR_DEV bool traverse(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, Hit&
 #define NR_CSWAP(ka, ca, kb, cb) { bool sw = kb < ka; float tk = sw ? kb : ka; kb = sw ? ka : kb; ka = tk; int32_t tc = sw ? cb : ca; cb = sw ? ca : cb; ca = tc; }
                 NR_CSWAP(k0, c0, k1, c1) NR_CSWAP(k2, c2, k3, c3) NR_CSWAP(k0, c0, k2, c2) NR_CSWAP(k1, c1, k3, c3) NR_CSWAP(k1, c1, k2, c2)
 #undef NR_CSWAP
-                if (k3 < kMiss) st.push(c3);
-                if (k2 < kMiss) st.push(c2);
-                if (k1 < kMiss) st.push(c1);
+                if (__builtin_expect(st.sp <= kLdsStack - 3, 1)) {
+                    // the common case, without a branch per child: every candidate is written, a miss is overwritten by
+                    // the next one (the keys are sorted, so the misses come first in this farthest-first order)
+                    int a = st.sp;
+                    st.lds[a * kBlock] = (uint32_t)c3; a += k3 < kMiss ? 1 : 0;
+                    st.lds[a * kBlock] = (uint32_t)c2; a += k2 < kMiss ? 1 : 0;
+                    st.lds[a * kBlock] = (uint32_t)c1; a += k1 < kMiss ? 1 : 0;
+                    st.sp = a;
+                } else {
+                    if (k3 < kMiss) st.push(c3);
+                    if (k2 < kMiss) st.push(c2);
+                    if (k1 < kMiss) st.push(c1);
+                }
                 if (k0 < kMiss) cur = c0;
                 else cur = st.sp ? st.pop() : kEmptyChild;
             } else {
                 // shadow rays are any-hit (or per-node closest with a result that does not depend on the
-                // visiting order): no sort, every hit child but the last found goes onto the stack
-                cur = kEmptyChild;
-                if (k0 < kMiss) cur = c0;
-                if (k1 < kMiss) { if (cur != kEmptyChild) st.push(cur); cur = c1; }
-                if (k2 < kMiss) { if (cur != kEmptyChild) st.push(cur); cur = c2; }
-                if (k3 < kMiss) { if (cur != kEmptyChild) st.push(cur); cur = c3; }
+                // visiting order): no sort, the last child hit is visited next, the others go onto the stack
+                const bool h0 = k0 < kMiss, h1 = k1 < kMiss, h2 = k2 < kMiss, h3 = k3 < kMiss;
+                cur = h3 ? c3 : (h2 ? c2 : (h1 ? c1 : (h0 ? c0 : kEmptyChild)));
+                const bool p0 = h0 && (h1 || h2 || h3), p1 = h1 && (h2 || h3), p2 = h2 && h3;
+                if (__builtin_expect(st.sp <= kLdsStack - 3, 1)) {
+                    int a = st.sp;
+                    st.lds[a * kBlock] = (uint32_t)c0; a += p0 ? 1 : 0;
+                    st.lds[a * kBlock] = (uint32_t)c1; a += p1 ? 1 : 0;
+                    st.lds[a * kBlock] = (uint32_t)c2; a += p2 ? 1 : 0;
+                    st.sp = a;
+                } else {
+                    if (p0) st.push(c0);
+                    if (p1) st.push(c1);
+                    if (p2) st.push(c2);
+                }
                 if (cur == kEmptyChild) cur = st.sp ? st.pop() : kEmptyChild;
             }
         }
