@@ -134,7 +134,8 @@ __global__ void __launch_bounds__(kBlock, waves_per_simd(FEAT)) k_primary(DScene
     st.lds = (lds_u32*)(lds_stack + threadIdx.x);
     st.spill_stride = gridDim.x * kBlock;
     st.spill = spill ? (global_u32*)(spill + (size_t)blockIdx.x * kBlock + threadIdx.x) : nullptr;
-    st.sp = 0;
+    st.lds0 = Stack::addr((lds_u32*)lds_stack);
+    st.init();
     Cnt cnt; cnt.node = cnt.tri = cnt.prim = cnt.hit = cnt.tex = cnt.shadow = cnt.refl = cnt.refr = cnt.max_depth = cnt.max_chain_nodes = 0;
 #ifdef NR_PHASE_TIMING
     cnt.cyc_node = cnt.cyc_leaf = cnt.cyc_other = cnt.cyc_tri = 0; cnt.wv_node = cnt.ln_node = cnt.wv_tri = cnt.ln_tri = 0; cnt.cyc_closest0 = cnt.cyc_closestN = cnt.cyc_shadow = 0; cnt.wv_uni = 0;
@@ -281,7 +282,8 @@ __global__ void __launch_bounds__(kBlock, NRAYS_WAVES_PER_SIMD) k_bounce(DScene 
     st.lds = (lds_u32*)(lds_stack + threadIdx.x);
     st.spill_stride = gridDim.x * kBlock;
     st.spill = spill ? (global_u32*)(spill + (size_t)blockIdx.x * kBlock + threadIdx.x) : nullptr;
-    st.sp = 0;
+    st.lds0 = Stack::addr((lds_u32*)lds_stack);
+    st.init();
     Cnt cnt; cnt.node = cnt.tri = cnt.prim = cnt.hit = cnt.tex = cnt.shadow = cnt.refl = cnt.refr = cnt.max_depth = cnt.max_chain_nodes = 0;
 #ifdef NR_PHASE_TIMING
     cnt.cyc_node = cnt.cyc_leaf = cnt.cyc_other = cnt.cyc_tri = 0; cnt.wv_node = cnt.ln_node = cnt.wv_tri = cnt.ln_tri = 0; cnt.cyc_closest0 = cnt.cyc_closestN = cnt.cyc_shadow = 0; cnt.wv_uni = 0;
@@ -751,7 +753,7 @@ int nrays_scene_create(const NraysSceneDesc* desc, NraysScene** out_scene) {
     // worst-case stack use: up to 3 deferred siblings per level of TLAS + BLAS (max_bvh_depth bounds each),
     // one sentinel, the plane pseudo-leaves, a little slack; whatever exceeds the LDS part spills to HBM
     {
-        uint32_t need = 6u * (uint32_t)(h.max_bvh_depth + 1) + (uint32_t)h.planes.size() + 8u;
+        uint32_t need = 6u * (uint32_t)(h.max_bvh_depth + 1) + (uint32_t)h.planes.size() + 9u; // + the bottom marker
         sc->spill_entries = need > (uint32_t)kLdsStack ? need - (uint32_t)kLdsStack : 0u;
     }
     {

@@ -106,29 +106,42 @@ struct Cnt {
 };
 
 // ---------------------------------------------------------------- traversal stack ------------
-// Entries 0..kLdsStack-1 live in LDS, laid out [entry][lane] so a wave's access is conflict-free
-// (stride-1 dwords across lanes); deeper entries spill to a per-lane column in HBM.
+// Slots 0..kLdsStack-1 live in LDS, laid out [slot][lane] so a wave's access is conflict-free (stride-1 dwords across
+// lanes); deeper slots spill to a per-lane column in HBM.  Slot 0 holds a permanent kEmptyChild: popping an "empty"
+// stack returns the end-of-traversal marker without a test.  `top` is the LDS ADDRESS of the next free slot, so the hot
+// push is one ds_write + one add and the hot pop one add + one ds_read; whether ANY lane of the wave is near / beyond the
+// LDS part is one ballot on that address (a scalar branch around the rare general code, no per-lane branch).
 typedef __attribute__((address_space(3))) uint32_t lds_u32;    // explicitly LDS: ds_read / ds_write, never a generic flat access
 typedef __attribute__((address_space(1))) uint32_t global_u32; // explicitly global memory
 struct Stack {
-    lds_u32* lds;      // &lds_stack[threadIdx.x]
+    lds_u32* lds;      // &lds_stack[threadIdx.x] = slot 0 of this lane
+    lds_u32* top;      // lds + n * kBlock, n = slots in use (the bottom marker included); beyond the LDS part only its value counts
     global_u32* spill; // &spill[global lane]   (may be null when the tree depth fits in LDS)
     uint32_t spill_stride;
-    int sp;
-    NR_DEV void push(int32_t v) {
-        if (sp < kLdsStack) lds[sp * kBlock] = (uint32_t)v;
-        else spill[(size_t)(sp - kLdsStack) * spill_stride] = (uint32_t)v;
-        ++sp;
+    uint32_t lds0;     // uniform: LDS address of lds_stack[0]
+    NR_DEV static uint32_t addr(const lds_u32* p) { return (uint32_t)(uintptr_t)p; }
+    NR_DEV void init() { lds[0] = (uint32_t)kEmptyChild; top = lds + kBlock; } // once per kernel: nothing ever overwrites slot 0
+    NR_DEV void reset() { top = lds + kBlock; }
+    NR_DEV int slots() const { return (int)(top - lds) / kBlock; }
+    // true iff every active lane of the wave can take `n` more slots inside the LDS part
+    NR_DEV bool wave_has_room(int n) const { return __ballot(addr(top) >= lds0 + (uint32_t)(kLdsStack - n + 1) * kBlock * 4u) == 0; }
+    NR_DEV void push(int32_t v) { // general form
+        const int n = slots();
+        if (n < kLdsStack) *top = (uint32_t)v;
+        else spill[(size_t)(n - kLdsStack) * spill_stride] = (uint32_t)v;
+        top += kBlock;
     }
     NR_DEV int32_t pop() {
-        --sp;
-        // The LDS read is unconditional (clamped slot) and the HBM column only overrides it in its own, rare branch:
-        // written as `sp < kLdsStack ? lds[..] : spill[..]` the compiler selects between the two POINTERS and issues
-        // one generic flat_load — on the critical path of the node loop, counted against vmcnt and lgkmcnt alike.
-        // (`volatile`: the optimiser otherwise sinks this read below the branch and merges the two loads again.)
-        int32_t v = (int32_t)*(volatile lds_u32*)&lds[(sp < kLdsStack ? sp : kLdsStack - 1) * kBlock];
-        if (__builtin_expect(sp >= kLdsStack, 0)) v = (int32_t)spill[(size_t)(sp - kLdsStack) * spill_stride];
-        return v;
+        top -= kBlock;
+        if (__builtin_expect(__ballot(addr(top) >= lds0 + (uint32_t)kLdsStack * kBlock * 4u) != 0, 0)) { // some lane is in its HBM column
+            const int n = slots();
+            // two explicit accesses: written as one conditional expression the compiler selects between the POINTERS and
+            // issues a generic flat_load
+            int32_t v = (int32_t)*(volatile lds_u32*)&lds[(n < kLdsStack ? n : kLdsStack - 1) * kBlock];
+            if (n >= kLdsStack) v = (int32_t)spill[(size_t)(n - kLdsStack) * spill_stride];
+            return v;
+        }
+        return (int32_t)*top;
     }
 };
 
@@ -783,7 +796,7 @@ NR_DEV bool traverse(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, Hit&
     float btf = best_f32(bt);
     bool in_blas = false;
     uint32_t cur_inst = 0, cur_flags = 0;
-    st.sp = 0;
+    st.reset();
     // planes have infinite AABBs (ncollide Plane AABB = +-MAX): kept out of the BVH and visited as
     // pseudo-leaves, pushed first so that they are tested after the TLAS has tightened the bound.
     if (kAnalytic) {
@@ -791,7 +804,7 @@ NR_DEV bool traverse(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, Hit&
         for (uint32_t p = 0; p < S.num_planes; ++p) st.push(~(int32_t)(((uint32_t)planes[p]) << 3));
     }
     int32_t cur = SHADOW ? S.shadow_root : S.closest_root;
-    if (cur == kEmptyChild && st.sp) cur = st.pop();
+    if (cur == kEmptyChild) cur = st.pop();
 
     // "while-while" traversal: the wave first runs internal-node steps only (one 64-byte fetch and two
     // f32 box tests per step) until every lane holds a leaf or is done, then runs the leaf code, instead
@@ -818,39 +831,39 @@ NR_DEV bool traverse(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, Hit&
 #define NR_CSWAP(ka, ca, kb, cb) { bool sw = kb < ka; float tk = sw ? kb : ka; kb = sw ? ka : kb; ka = tk; int32_t tc = sw ? cb : ca; cb = sw ? ca : cb; ca = tc; }
                 NR_CSWAP(k0, c0, k1, c1) NR_CSWAP(k2, c2, k3, c3) NR_CSWAP(k0, c0, k2, c2) NR_CSWAP(k1, c1, k3, c3) NR_CSWAP(k1, c1, k2, c2)
 #undef NR_CSWAP
-                if (__builtin_expect(st.sp <= kLdsStack - 3, 1)) {
+                if (__builtin_expect(st.wave_has_room(3), 1)) {
                     // the common case, without a branch per child: every candidate is written, a miss is overwritten by
-                    // the next one (the keys are sorted, so the misses come first in this farthest-first order)
-                    int a = st.sp;
-                    st.lds[a * kBlock] = (uint32_t)c3; a += k3 < kMiss ? 1 : 0;
-                    st.lds[a * kBlock] = (uint32_t)c2; a += k2 < kMiss ? 1 : 0;
-                    st.lds[a * kBlock] = (uint32_t)c1; a += k1 < kMiss ? 1 : 0;
-                    st.sp = a;
+                    // the next one
+                    lds_u32* a = st.top;
+                    *a = (uint32_t)c3; a += k3 < kMiss ? kBlock : 0;
+                    *a = (uint32_t)c2; a += k2 < kMiss ? kBlock : 0;
+                    *a = (uint32_t)c1; a += k1 < kMiss ? kBlock : 0;
+                    st.top = a;
                 } else {
                     if (k3 < kMiss) st.push(c3);
                     if (k2 < kMiss) st.push(c2);
                     if (k1 < kMiss) st.push(c1);
                 }
                 if (k0 < kMiss) cur = c0;
-                else cur = st.sp ? st.pop() : kEmptyChild;
+                else cur = st.pop();
             } else {
                 // shadow rays are any-hit (or per-node closest with a result that does not depend on the
                 // visiting order): no sort, the last child hit is visited next, the others go onto the stack
                 const bool h0 = k0 < kMiss, h1 = k1 < kMiss, h2 = k2 < kMiss, h3 = k3 < kMiss;
                 cur = h3 ? c3 : (h2 ? c2 : (h1 ? c1 : (h0 ? c0 : kEmptyChild)));
                 const bool p0 = h0 && (h1 || h2 || h3), p1 = h1 && (h2 || h3), p2 = h2 && h3;
-                if (__builtin_expect(st.sp <= kLdsStack - 3, 1)) {
-                    int a = st.sp;
-                    st.lds[a * kBlock] = (uint32_t)c0; a += p0 ? 1 : 0;
-                    st.lds[a * kBlock] = (uint32_t)c1; a += p1 ? 1 : 0;
-                    st.lds[a * kBlock] = (uint32_t)c2; a += p2 ? 1 : 0;
-                    st.sp = a;
+                if (__builtin_expect(st.wave_has_room(3), 1)) {
+                    lds_u32* a = st.top;
+                    *a = (uint32_t)c0; a += p0 ? kBlock : 0;
+                    *a = (uint32_t)c1; a += p1 ? kBlock : 0;
+                    *a = (uint32_t)c2; a += p2 ? kBlock : 0;
+                    st.top = a;
                 } else {
                     if (p0) st.push(c0);
                     if (p1) st.push(c1);
                     if (p2) st.push(c2);
                 }
-                if (cur == kEmptyChild) cur = st.sp ? st.pop() : kEmptyChild;
+                if (cur == kEmptyChild) cur = st.pop();
             }
         }
         NR_TOC(cyc_node, tphase);
@@ -867,7 +880,7 @@ NR_DEV bool traverse(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, Hit&
                 }
                 bt = tlimit; bkey = ~0ULL; bhit = false; btf = best_f32(bt);
             }
-            cur = st.sp ? st.pop() : kEmptyChild;
+            cur = st.pop();
             continue;
         }
         // leaf: ~cur = (first << 3) | bits.  Triangle leaves: bits = count - 1.  TLAS leaves: bits = kLeaf* flags.
@@ -877,7 +890,7 @@ NR_DEV bool traverse(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, Hit&
             NR_TIC(ttri);
             const float4* tq = (const float4*)(S.tris + first);
             float4 p0 = tq[0], p1 = tq[1], p2 = tq[2];
-            const int32_t after_leaf = st.sp ? st.pop() : kEmptyChild; // popped now: the LDS latency hides behind the tests
+            const int32_t after_leaf = st.pop(); // popped now: the LDS latency hides behind the tests
 #pragma nounroll
             for (uint32_t k = 0; k <= bits; ++k) {
                 const float4 t0 = p0, t1 = p1, t2 = p2;
@@ -936,7 +949,7 @@ NR_DEV bool traverse(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, Hit&
                 }
             }
         }
-        cur = st.sp ? st.pop() : kEmptyChild;
+        cur = st.pop();
     }
 
     if (SHADOW) return false;
