@@ -187,6 +187,15 @@ struct DRender {
     uint32_t first_batch;        // 1: the frame starts here, 0: a later sample batch continues the running sums in `out`
     uint32_t use_rng;            // 0 when no random number can be consumed (window == 0, no area light)
     uint32_t lane_log2;          // log2 of the lanes that share one pixel (sample-major mapping of AA frames; 0 = one lane per pixel)
+    // Pixels outside [cull_i0, cull_i1] x [cull_j0, cull_j1] (global column / row) cannot reach the scene's bounding box
+    // with any of their primary rays: a wave tile without a pixel inside writes the background without generating a ray
+    // (nrays_hip.hip: screen_bounds()).  INT_MIN / INT_MAX = every pixel may hit (camera inside the box, planes, ...).
+    int32_t cull_i0, cull_i1, cull_j0, cull_j1;
+    // The same bounds in units of scheduling blocks (16 x 16 pixels at one lane per pixel, the wave's pixel block of an
+    // anti-aliased frame), local rows: only the blocks [win_x0, win_x0 + win_nx) x [win_y0, win_y0 + win_ny) enter the
+    // work lists; the pixels of all other blocks are filled with the background by the kernel's prologue.  Equal to the
+    // whole frame when nothing can be decided (or when the frame is rendered in several sample batches).
+    uint32_t win_x0, win_nx, win_y0, win_ny;
     double window_width;
     double eye[3];
     double m[16];                // (P V)^-1 column-major

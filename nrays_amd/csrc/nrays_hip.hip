@@ -16,6 +16,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <climits>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -150,7 +152,29 @@ __global__ void __launch_bounds__(kBlock, waves_per_simd(FEAT)) k_primary(DScene
     // (tot_c = tot_c + trace(ray), scene.rs:72-91) by an in-wave ordered reduction, so the frame is bit-identical to the
     // pixel-major one.  One lane per pixel (lane_log2 = 0): wave tiles are 8x8, four per 16x16 block.
     const uint32_t lane_log2 = PLAIN ? 0u : R.lane_log2;
-    const uint32_t nwt = lane_log2 ? tiles_x * tiles_y : tiles_x * tiles_y * 4u;
+    const uint32_t nwt = lane_log2 ? R.win_nx * R.win_ny : R.win_nx * R.win_ny * 4u; // wave tiles of the window (device_types.h: DRender::win_*)
+
+    // Prologue: the pixels outside the window cannot be reached by the scene (screen_bounds()): every sample returns the
+    // background, the pixel holds their f32 sum in sample order (padding rows of the last band: zero).  Rows are dealt
+    // round-robin to the workgroups; the window's own pixels are written by the tiles below, so no pixel has two writers.
+    if (R.win_nx < tiles_x || R.win_ny < tiles_y) {
+        const uint32_t bwl = lane_log2 ? (7u - lane_log2) >> 1 : 4u, bhl = lane_log2 ? (6u - lane_log2) >> 1 : 4u;
+        const uint32_t wi0 = R.win_x0 << bwl, wi1 = (R.win_x0 + R.win_nx) << bwl, wr0 = R.win_y0 << bhl, wr1 = (R.win_y0 + R.win_ny) << bhl;
+        float b0 = 0.0f, b1 = 0.0f, b2 = 0.0f;
+        for (uint32_t s = 0; s < R.spp; ++s) { b0 = b0 + S.background[0]; b1 = b1 + S.background[1]; b2 = b2 + S.background[2]; }
+        for (uint32_t rl = blockIdx.x; rl < R.rows_local; rl += gridDim.x) {
+            uint32_t j = rl;
+            if (R.band_rows != 0 && R.band_owners > 1) j = ((rl / R.band_rows) * R.band_owners + R.band_owner) * R.band_rows + (rl % R.band_rows);
+            const bool real = j < R.height;
+            const bool split = rl >= wr0 && rl < wr1 && R.win_nx != 0u; // this row crosses the window: skip its columns
+            float* row = out + (size_t)rl * R.width * 3;
+            for (uint32_t f = threadIdx.x; f < R.width * 3u; f += kBlock) {
+                const uint32_t i = f / 3u, c = f - i * 3u;
+                if (split && i >= wi0 && i < wi1) continue;
+                row[f] = real ? (c == 0u ? b0 : (c == 1u ? b1 : b2)) : 0.0f;
+            }
+        }
+    }
 
     // grab == 0 (cheap analytic scenes, ~1 us tiles): the wave tiles are dealt round-robin to the workgroups and
     // the four waves of a workgroup pull from their list through an LDS counter — list scheduling inside the
@@ -202,14 +226,14 @@ __global__ void __launch_bounds__(kBlock, waves_per_simd(FEAT)) k_primary(DScene
         uint32_t q = 0u; // which of the pixel's side-by-side samples this lane traces
         if (lane_log2 == 0u) {
             uint32_t tile = wt >> 2, sub = wt & 3u;
-            uint32_t tx = tile % tiles_x, ty = tile / tiles_x;
+            uint32_t tx = R.win_x0 + tile % R.win_nx, ty = R.win_y0 + tile / R.win_nx;
             uint32_t lx = ((sub & 1u) << 3) | (lane & 7u), ly = ((sub >> 1) << 3) | (lane >> 3);
             i = tx * kTile + lx; rl = ty * kTile + ly;
         } else {
             const uint32_t bwl = (7u - lane_log2) >> 1, bhl = (6u - lane_log2) >> 1; // the wave's pixel block is 2^bwl x 2^bhl
             const uint32_t p = lane >> lane_log2;
             q = lane & ((1u << lane_log2) - 1u);
-            uint32_t tx = wt % tiles_x, ty = wt / tiles_x;
+            uint32_t tx = R.win_x0 + wt % R.win_nx, ty = R.win_y0 + wt / R.win_nx;
             i = (tx << bwl) + (p & ((1u << bwl) - 1u)); rl = (ty << bhl) + (p >> bwl);
         }
         // local row -> global row (framebuffer bands dealt round-robin to owners)
@@ -220,6 +244,9 @@ __global__ void __launch_bounds__(kBlock, waves_per_simd(FEAT)) k_primary(DScene
         }
         bool active = i < R.width && rl < R.rows_local && j < R.height;
         uint32_t pix = rl * R.width + i;
+        // no pixel of this wave tile inside the screen bounds of the scene: every sample is a miss (Scene::trace returns the
+        // background, scene.rs:157-161) and no ray has to be generated to know it
+        const bool tile_misses = __ballot(active && (int32_t)i >= R.cull_i0 && (int32_t)i <= R.cull_i1 && (int32_t)j >= R.cull_j0 && (int32_t)j <= R.cull_j1) == 0ULL;
         // tot_c = tot_c + trace(ray) sample after sample (scene.rs:72-91): a later sample batch continues the running sum
         // of the earlier ones, so the f32 summation order — and with it the frame — does not depend on the batching
         f3 tot = F3(0.0f, 0.0f, 0.0f);
@@ -229,16 +256,20 @@ __global__ void __launch_bounds__(kBlock, waves_per_simd(FEAT)) k_primary(DScene
             const uint32_t s = g + q;
             const bool sample_active = active && s < s_end;
             RayState ray;
-            // lanes outside the frame (ragged right edge, padding rows of a band) still execute the ray generation: keep their
-            // table reads inside the tables
-            generate_primary<PLAIN>(R, i < R.width ? i : R.width - 1u, j < R.height ? j : R.height - 1u, s, pix, ray);
             unsigned node_before = cnt.node;
             f3 c;
-            if (__ballot(sample_active && primary_may_hit(S, ray.o, ray.d)) == 0ULL) {
+            bool wave_may_hit = false; // wave-uniform
+            if (!tile_misses) {
+                // lanes outside the frame (ragged right edge, padding rows of a band) still execute the ray generation: keep
+                // their table reads inside the tables
+                generate_primary<PLAIN>(R, i < R.width ? i : R.width - 1u, j < R.height ? j : R.height - 1u, s, pix, ray);
+                wave_may_hit = __ballot(sample_active && primary_may_hit(S, ray.o, ray.d)) != 0ULL;
+            }
+            if (!wave_may_hit) {
                 // no ray of this wave tile gets past the root of the BVT: Scene::trace returns the background for
                 // all of them (scene.rs:157-161), without entering the trace loop
                 c = F3(S.background[0], S.background[1], S.background[2]);
-                if (STATS && sample_active && S.closest_root >= 0) cnt.node += root_children(S);
+                if (STATS && !tile_misses && sample_active && S.closest_root >= 0) cnt.node += root_children(S);
             } else {
                 c = trace_chain<STATS, FEAT>(S, st, sample_active, ray, 0u, R.max_depth, qo, cnt, !PLAIN && R.use_rng != 0u);
             }
@@ -329,6 +360,69 @@ __global__ void __launch_bounds__(1024) k_tile_order(const uint32_t* __restrict_
     }
     __syncthreads();
     for (uint32_t i = x + 8u * threadIdx.x; i < n; i += 8u * 1024u) order[8u * atomicAdd(&hist[cost_bucket(cost[i])], 1u) + x] = i;
+}
+
+// Screen bounds of the scene for one camera: the pixel rectangle outside of which no primary ray can reach the scene's
+// bounding box, so that k_primary can write the background for whole wave tiles without generating their rays.
+// Raygen (generate_primary, scene.rs:74-89) sends the ray of sample position (ox, oy) from `eye` through
+// P = h.xyz / h.w with h = M (dx, dy, -1, 1), dx = (ox / W - 0.5) 2, dy = -(oy / H - 0.5) 2; its direction is a positive
+// multiple of sgn(h.w) D(dx, dy), D = h.xyz - eye h.w = Dc + dx Dx + dy Dy — AFFINE in (dx, dy).  A corner c of the
+// box lies on the ray of (dx, dy) iff c - eye = a Dc + b Dx + g Dy with dx = b / a, dy = g / a and a sgn > 0 (in front).
+// If that holds for all eight corners, every point of the box is a combination of the corners with weights of one sign,
+// so its (dx, dy) lies between the corners' extremes: rays outside that rectangle miss the box, hence every node, hence
+// return the background; a box entirely behind the eye is missed by every ray.  Everything else — a corner beside the eye, h.w changing sign over the frame, a
+// degenerate matrix, planes in the scene — gives "every pixel may hit".  Two pixels of slack plus the jitter window
+// cover the rounding of this f64 computation and of the rays themselves by many orders of magnitude.
+struct ScreenBounds { int32_t i0, i1, j0, j1; };
+static ScreenBounds screen_bounds(const HostScene& h, const NraysRenderParams* p) {
+    const ScreenBounds all = {INT32_MIN, INT32_MAX, INT32_MIN, INT32_MAX}, none = {0, -1, 0, -1};
+    if (!h.bounded) return all;
+    for (int a = 0; a < 3; ++a) {
+        if (!(h.bounds_mn[a] <= h.bounds_mx[a])) return none; // no bounded node at all
+        if (!std::isfinite(h.bounds_mn[a]) || !std::isfinite(h.bounds_mx[a])) return all;
+    }
+    const double* M = p->inv_proj_view; // column-major
+    const double* e = p->camera_eye;
+    double hc[4], hx[4], hy[4];
+    for (int r = 0; r < 4; ++r) { hc[r] = M[12 + r] - M[8 + r]; hx[r] = M[r]; hy[r] = M[4 + r]; }
+    // h.w keeps one sign over the frame (it is affine in dx, dy: check the corners of a slightly larger rectangle)
+    const double ext = 1.0 + 4.0 / std::min<double>(p->width, p->height) + std::fabs(p->window_width);
+    double wmin = INFINITY, wmax = -INFINITY, wscale = std::fabs(hc[3]) + std::fabs(hx[3]) + std::fabs(hy[3]);
+    for (int k = 0; k < 4; ++k) { double w = hc[3] + ((k & 1) ? ext : -ext) * hx[3] + ((k & 2) ? ext : -ext) * hy[3]; wmin = std::min(wmin, w); wmax = std::max(wmax, w); }
+    if (!(wscale > 0.0) || !std::isfinite(wscale) || !(wmin > 1e-9 * wscale || wmax < -1e-9 * wscale)) return all;
+    const double sgn = wmin > 0.0 ? 1.0 : -1.0;
+    double Dc[3], Dx[3], Dy[3];
+    for (int a = 0; a < 3; ++a) { Dc[a] = hc[a] - e[a] * hc[3]; Dx[a] = hx[a] - e[a] * hx[3]; Dy[a] = hy[a] - e[a] * hy[3]; }
+    auto det3 = [](const double* u, const double* v, const double* w) {
+        return u[0] * (v[1] * w[2] - v[2] * w[1]) - u[1] * (v[0] * w[2] - v[2] * w[0]) + u[2] * (v[0] * w[1] - v[1] * w[0]);
+    };
+    auto len = [](const double* v) { return std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); };
+    const double det = det3(Dc, Dx, Dy);
+    if (!std::isfinite(det) || !(std::fabs(det) > 1e-9 * len(Dc) * len(Dx) * len(Dy))) return all;
+    double xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
+    double A[8], B[8], G[8];
+    int behind = 0;
+    for (int k = 0; k < 8; ++k) {
+        double c[3];
+        for (int a = 0; a < 3; ++a) c[a] = (double)((k >> a) & 1 ? h.bounds_mx[a] : h.bounds_mn[a]) - e[a];
+        A[k] = det3(c, Dx, Dy) / det; B[k] = det3(Dc, c, Dy) / det; G[k] = det3(Dc, Dx, c) / det; // Cramer
+        if (!std::isfinite(A[k]) || !std::isfinite(B[k]) || !std::isfinite(G[k])) return all;
+        if (A[k] * sgn < -1e-9 * (std::fabs(A[k]) + std::fabs(B[k]) + std::fabs(G[k]))) ++behind;
+    }
+    if (behind == 8) return none; // the whole box lies behind the eye: its points are NEGATIVE multiples of every ray direction
+    for (int k = 0; k < 8; ++k) {
+        const double a_ = A[k], b_ = B[k], g_ = G[k];
+        if (!(a_ * sgn > 1e-9 * (std::fabs(a_) + std::fabs(b_) + std::fabs(g_)))) return all; // beside / behind the eye
+        const double dx = b_ / a_, dy = g_ / a_;
+        if (!std::isfinite(dx) || !std::isfinite(dy)) return all;
+        const double ox = (dx * 0.5 + 0.5) * (double)p->width, oy = (-dy * 0.5 + 0.5) * (double)p->height;
+        xmin = std::min(xmin, ox); xmax = std::max(xmax, ox); ymin = std::min(ymin, oy); ymax = std::max(ymax, oy);
+    }
+    // pixel i takes its samples at ox in [i - window / 2, i + window / 2]
+    const double slack = 2.0 + 0.5 * std::fabs(p->window_width);
+    auto clampi = [](double v) { return (int32_t)std::max(-1.0e9, std::min(1.0e9, v)); };
+    ScreenBounds r = {clampi(std::floor(xmin - slack)), clampi(std::ceil(xmax + slack)), clampi(std::floor(ymin - slack)), clampi(std::ceil(ymax + slack))};
+    return r;
 }
 
 // Per-column / per-row raygen products for jitter-free cameras (see DRender::col_tab): thread t < width
@@ -437,6 +531,7 @@ struct NraysScene {
     bool last_timed = true;
     int grab_override = -1;                         // NRAYS_GRAB
     bool lpt_enabled = true;                        // NRAYS_LPT=0 restores image order
+    bool cull_enabled = true;                       // NRAYS_SCREEN_CULL=0: no wave tile is decided from the scene's screen bounds
     NraysStats last;
     uint64_t last_primary = 0, last_primary_first_batch = 0;
     bool last_instrumented = false;
@@ -563,6 +658,8 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
     for (int a = 0; a < 3; ++a) R.eye[a] = p->camera_eye[a];
     for (int a = 0; a < 16; ++a) R.m[a] = p->inv_proj_view[a];
     R.seed = p->seed;
+    { const ScreenBounds sb = sc->cull_enabled ? screen_bounds(sc->host, p) : ScreenBounds{INT32_MIN, INT32_MAX, INT32_MIN, INT32_MAX};
+      R.cull_i0 = sb.i0; R.cull_i1 = sb.i1; R.cull_j0 = sb.j0; R.cull_j1 = sb.j1; }
 
     // lanes per pixel of an anti-aliased frame (sample-major mapping, see k_primary): the largest power of two <= min(batch, 64)
     uint32_t lane_log2 = 0;
@@ -572,6 +669,26 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
     const uint32_t bwl = lane_log2 ? (7u - lane_log2) >> 1 : 4u, bhl = lane_log2 ? (6u - lane_log2) >> 1 : 4u; // pixel block of a scheduling unit
     const uint32_t tiles_x = (p->width + (1u << bwl) - 1) >> bwl, tiles_y = (rows + (1u << bhl) - 1) >> bhl;
     const uint32_t ntiles = lane_log2 ? (tiles_x * tiles_y + 3u) / 4u : tiles_x * tiles_y; // in units of four wave tiles
+    // window of scheduling blocks that can see the scene (DRender::win_*); a block row of the compact buffer maps to
+    // consecutive global rows as long as the bands are whole blocks high
+    R.win_x0 = 0; R.win_nx = tiles_x; R.win_y0 = 0; R.win_ny = tiles_y;
+    const bool banded = p->band_rows != 0 && R.band_owners > 1;
+    if (batch >= p->ray_per_pixel && !instrumented && (!banded || p->band_rows % (1u << bhl) == 0) && (R.cull_i0 != INT32_MIN || R.cull_i1 != INT32_MAX)) {
+        const int64_t i0 = std::max<int64_t>(R.cull_i0, 0), i1 = std::min<int64_t>(R.cull_i1, (int64_t)p->width - 1);
+        uint32_t x0 = 0, nx = 0, y0 = 0, ny = 0;
+        if (i0 <= i1) { x0 = (uint32_t)(i0 >> bwl); nx = (uint32_t)(i1 >> bwl) - x0 + 1u; }
+        for (uint32_t by = 0; by < tiles_y && nx; ++by) {
+            const uint32_t rl0 = by << bhl;
+            const int64_t j0 = banded ? (int64_t)((rl0 / p->band_rows) * R.band_owners + R.band_owner) * p->band_rows + (rl0 % p->band_rows) : (int64_t)rl0;
+            const int64_t j1 = std::min<int64_t>(j0 + (1 << bhl) - 1, (int64_t)p->height - 1);
+            if (j0 > j1 || j1 < R.cull_j0 || j0 > R.cull_j1) continue; // padding rows / outside the bounds
+            if (ny == 0) y0 = by;
+            ny = by - y0 + 1u;
+        }
+        if (ny == 0) nx = 0;
+        R.win_x0 = x0; R.win_nx = nx; R.win_y0 = y0; R.win_ny = ny;
+    }
+    const uint32_t win_units = R.win_nx * R.win_ny; // scheduling blocks inside the window
     uint32_t grab = sc->host.any_mesh ? 1u : 0u; // 0 = workgroup lists through LDS; the specialised kernels fix their path at compile time
     if (sc->grab_override >= 0) grab = (uint32_t)sc->grab_override; // tiles per dequeue of the mesh kernels, A/B only (NRAYS_GRAB); pixels do not depend on it
     // persistent grid: exactly the workgroups that can be resident (one 4-wave workgroup per CU per wave/SIMD)
@@ -619,7 +736,7 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
     bool lpt = grab >= 1u;
     lpt = lpt && sc->lpt_enabled; // A/B switch (NRAYS_LPT=0)
     if (lpt) {
-        const uint32_t nwt = lane_log2 ? tiles_x * tiles_y : ntiles * 4u;
+        const uint32_t nwt = std::max<uint32_t>(1u, lane_log2 ? win_units : win_units * 4u);
         if (nwt > sc->tile_slots) {
             if (sc->d_tile_cost) { (void)hipFree(sc->d_tile_cost); sc->d_tile_cost = nullptr; }
             if (sc->d_tile_order) { (void)hipFree(sc->d_tile_order); sc->d_tile_order = nullptr; }
@@ -628,7 +745,8 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
             HIP_TRY(hipMalloc((void**)&sc->d_tile_order, (size_t)nwt * sizeof(uint32_t)));
             sc->tile_slots = nwt;
         }
-        const uint64_t key = ((uint64_t)p->width << 40) ^ ((uint64_t)rows << 20) ^ ((uint64_t)p->band_rows << 8) ^ ((uint64_t)p->band_owner << 4) ^ (uint64_t)R.band_owners ^ ((uint64_t)lane_log2 << 60);
+        const uint64_t key = (((uint64_t)p->width << 40) ^ ((uint64_t)rows << 20) ^ ((uint64_t)p->band_rows << 8) ^ ((uint64_t)p->band_owner << 4) ^ (uint64_t)R.band_owners ^ ((uint64_t)lane_log2 << 60))
+                             + 0x9E3779B97F4A7C15ull * (((uint64_t)R.win_x0 << 48) ^ ((uint64_t)R.win_nx << 32) ^ ((uint64_t)R.win_y0 << 16) ^ (uint64_t)R.win_ny);
         if (sc->cost_valid && sc->cost_key == key) {
             if (timed) HIP_TRY(hipEventRecord(sc->ev_begin[slot], stream));
             sc->has_prepass[slot] = true;
@@ -766,6 +884,7 @@ int nrays_scene_create(const NraysSceneDesc* desc, NraysScene** out_scene) {
     if (const char* e = getenv("NRAYS_EVENT_STRIDE")) sc->event_stride = (uint32_t)std::max(1, atoi(e));
     if (const char* e = getenv("NRAYS_GRAB")) sc->grab_override = std::max(0, atoi(e));
     if (const char* e = getenv("NRAYS_LPT")) sc->lpt_enabled = atoi(e) != 0;
+    if (const char* e = getenv("NRAYS_SCREEN_CULL")) sc->cull_enabled = atoi(e) != 0;
     // release bulk host copies
     std::vector<BvhNode>().swap(h.nodes); std::vector<TriRec>().swap(h.tris); std::vector<TriUv>().swap(h.triuvs);
 

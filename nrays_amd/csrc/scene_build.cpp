@@ -610,6 +610,9 @@ int build_host_scene(const NraysSceneDesc* d, HostScene& out, std::string& err) 
         if (!(d->num_lights == 1 && d->lights[0].racsample == 1)) f |= 16; // more than one light sample per hit
         out.features = f;
     }
+    out.bounded = planes_c.empty();
+    for (int a = 0; a < 3; ++a) { out.bounds_mn[a] = std::numeric_limits<float>::infinity(); out.bounds_mx[a] = -std::numeric_limits<float>::infinity(); }
+    for (const PrimBounds& b : cbox) for (int a = 0; a < 3; ++a) { out.bounds_mn[a] = std::min(out.bounds_mn[a], b.mn[a]); out.bounds_mx[a] = std::max(out.bounds_mx[a], b.mx[a]); }
     out.closest_root = append_tlas(cinst, cbox, out);
     out.shadow_root = append_tlas(sinst, sbox, out);
     for (size_t k = 0; k < planes_c.size(); ++k) {

@@ -39,6 +39,10 @@ struct HostScene {
     bool any_mesh = false;          // some TriMesh node has triangles (decides the tile scheduling path)
     uint32_t reflection_generations = 0; // upper bound from the energy rule (scene.rs:204-206)
     int max_bvh_depth = 0;
+    // f32 box (rounded outward) around every bounded node = the boxes of the closest-hit TLAS; `bounded` is false when
+    // a plane (unbounded) is present.  Used to find the pixels whose primary rays cannot hit anything (screen_bounds()).
+    bool bounded = false;
+    float bounds_mn[3] = {0, 0, 0}, bounds_mx[3] = {0, 0, 0};
     int features = 0;              // Features bits of trace_device.h: which kernel permutation renders this scene
 };
 

@@ -1,0 +1,119 @@
+"""Screen bounds of the scene (nrays_hip.hip: screen_bounds()): wave tiles without a pixel inside the projected bounding box
+of the scene write the background without generating a ray.  It must never change a pixel or a ray count: every frame here
+is rendered by two handles of the same scene, one with the bounds in use and one created under NRAYS_SCREEN_CULL=0, and
+compared bit for bit (and a few against the oracle, which knows nothing of screen bounds).  Cameras: the bench view, the
+scene far away / off to one side / partly outside the frame / behind the camera, the eye inside the bounding box, a ray
+grazing a ball, jittered anti-aliased frames (the window widens the bounds), band tiling, ragged resolutions."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+import nrays_amd as nr
+import oracle
+from nrays_amd import abi
+from tests import scenes_util as su
+
+pytestmark = pytest.mark.gpu
+CLASSES = ("rays_primary", "rays_reflection", "rays_refraction", "rays_shadow")
+
+
+def _render(scene, p):
+    out = np.empty((p.height, p.width, 3), dtype=np.float32)
+    rows = p.height
+    if p.band_owners > 1:  # compact buffer of one owner's bands
+        from nrays_amd import tiling
+        rows = tiling.tile_rows(p.height, p.band_rows, p.band_owners)
+        out = np.empty((rows, p.width, 3), dtype=np.float32)
+    abi.check(abi.load_hip_lib().nrays_render(scene.device_handle(), C.byref(p), out.ctypes.data_as(C.POINTER(C.c_float))))
+    return out, nr.get_stats(scene)
+
+
+def _pair(make_scene, monkeypatch):
+    monkeypatch.delenv("NRAYS_SCREEN_CULL", raising=False)
+    a, cam = make_scene()
+    a.device_handle()
+    monkeypatch.setenv("NRAYS_SCREEN_CULL", "0")  # read once per handle, at creation
+    b, _ = make_scene()
+    b.device_handle()
+    monkeypatch.delenv("NRAYS_SCREEN_CULL", raising=False)
+    return a, b, cam
+
+
+CAMERAS = {
+    "bench view": dict(eye=(0.0, 5.0, -10.0), at=(0.0, 0.0, 0.0), fovy=45.0),
+    "far away": dict(eye=(0.0, 60.0, -240.0), at=(0.0, 0.0, 0.0), fovy=45.0),
+    "scene in a corner": dict(eye=(0.0, 5.0, -10.0), at=(9.0, 4.0, 0.0), fovy=45.0),
+    "scene cut by the frame edge": dict(eye=(0.0, 5.0, -10.0), at=(4.5, 0.0, 0.0), fovy=30.0),
+    "scene behind the camera": dict(eye=(0.0, 5.0, -10.0), at=(0.0, 10.0, -20.0), fovy=45.0),
+    "scene beside the camera": dict(eye=(0.0, 0.0, -2.0), at=(0.0, 0.0, -10.0), fovy=120.0),
+    "eye inside the bounding box": dict(eye=(1.05, 0.9, 0.0), at=(0.0, 0.0, 0.0), fovy=70.0),
+    "grazing": dict(eye=(-10.0, 1.0, 0.0), at=(10.0, 1.0000001, 0.0), fovy=20.0),
+    "wide angle": dict(eye=(0.0, 1.0, -3.2), at=(0.0, 0.0, 0.0), fovy=150.0),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CAMERAS))
+def test_balls_frames_do_not_depend_on_the_screen_bounds(gpu, monkeypatch, name):
+    a, b, _ = _pair(su.balls_scene, monkeypatch)
+    for (w, h) in ((640, 360), (333, 217)):
+        p, _ = su.camera_params(CAMERAS[name], w, h)
+        ia, sa = _render(a, p)
+        ib, sb = _render(b, p)
+        assert np.array_equal(ia, ib), name
+        for k in CLASSES:
+            assert getattr(sa, k) == getattr(sb, k), (name, k)
+    p, _ = su.camera_params(CAMERAS[name], 320, 180)
+    img, st = _render(a, p)
+    ref, ost = oracle.render(a.descriptor, p, 8)
+    assert np.abs(img - ref).max() <= 1e-4, name
+    for k in CLASSES:
+        assert getattr(st, k) == getattr(ost, k), (name, k)
+
+
+@pytest.mark.parametrize("spp,window", [(4, 1.0), (5, 7.0), (16, 2.5)])
+def test_jittered_frames_do_not_depend_on_the_screen_bounds(gpu, monkeypatch, spp, window):
+    """The jitter window moves a pixel's samples by up to window / 2 pixels: the bounds are widened by it."""
+    a, b, cam = _pair(su.balls_scene, monkeypatch)
+    far = dict(eye=(0.0, 20.0, -60.0), at=(6.0, 0.0, 0.0), fovy=45.0)
+    for c in (cam, far):
+        p, _ = su.camera_params(c, 480, 270, spp=spp, window=window, seed=11)
+        ia, sa = _render(a, p)
+        ib, sb = _render(b, p)
+        assert np.array_equal(ia, ib)
+        for k in CLASSES:
+            assert getattr(sa, k) == getattr(sb, k), k
+
+
+def test_mesh_scene_and_band_tiling(gpu, monkeypatch):
+    a, b, cam = _pair(lambda: su.mesh_scene(), monkeypatch)
+    far = dict(eye=(3.0, 14.0, -45.0), at=(0.0, 0.0, 0.0), fovy=40.0)
+    for c in (cam, far):
+        for owners, owner, band in ((1, 0, 0), (3, 1, 16), (2, 1, 1)):
+            p, _ = su.camera_params(c, 400, 232, band_rows=band, band_owner=owner, band_owners=owners)
+            ia, sa = _render(a, p)
+            ib, sb = _render(b, p)
+            assert np.array_equal(ia, ib), (owners, owner, band)
+            for k in CLASSES:
+                assert getattr(sa, k) == getattr(sb, k), k
+
+
+def test_degenerate_cameras_fall_back_to_every_pixel(gpu, monkeypatch):
+    """A singular / non-finite inverse projection must not crash or cull: whatever the kernel computes for such rays, it
+    computes it for every pixel, with and without the bounds."""
+    a, b, cam = _pair(su.balls_scene, monkeypatch)
+    p, proj = su.camera_params(cam, 160, 90)
+    for k in range(16):
+        p.inv_proj_view[k] = 0.0
+    p.inv_proj_view[15] = 1.0
+    ia, _ = _render(a, p)
+    ib, _ = _render(b, p)
+    assert np.array_equal(ia, ib, equal_nan=True)
+    # eye exactly on a face of the bounding box (x = 3.1 is the +x face of the right ball's box up to its f32 rounding)
+    c = dict(eye=(3.1, 0.0, 0.0), at=(0.0, 0.0, 0.0), fovy=60.0)
+    p, _ = su.camera_params(c, 160, 90)
+    ia, _ = _render(a, p)
+    ib, _ = _render(b, p)
+    assert np.array_equal(ia, ib)
+    assert not math.isnan(float(ia.sum()))

@@ -29,6 +29,12 @@ def run_one(scene_name, steps, width, height, check):
     elif scene_name == "ballsaway":  # every wave tile misses the scene: the cheap path alone
         sc, cam = su.balls_scene()
         cam = dict(cam, at=(0.0, 5.0, -30.0))
+    elif scene_name == "ballszoom":  # every pixel starts a deep reflection chain between the balls (use with a small frame)
+        sc, cam = su.balls_scene()
+        cam = dict(eye=(0.0, 0.6, -6.0), at=(1.05, 0.0, 0.0), fovy=6.0)
+    elif scene_name == "ballsfar":  # the scene covers a few wave tiles only: the cost of a tile outside its screen bounds
+        sc, cam = su.balls_scene()
+        cam = dict(cam, eye=(0.0, 150.0, -300.0))
     elif scene_name == "sponza":
         sc, cam = standins.sponza_scene()
     elif scene_name == "sponza8":
