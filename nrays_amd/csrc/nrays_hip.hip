@@ -196,6 +196,10 @@ __global__ void __launch_bounds__(kBlock, waves_per_simd(FEAT)) k_primary(DScene
           if (lane == 0u) k = atomicAdd(&block_next, 1u); // LDS: ~100 cycles, no prefetch needed
           first = (uint32_t)__builtin_amdgcn_readfirstlane((int)k) * gridDim.x + blockIdx.x;
           if (first >= nwt) break;
+          // with the costs of an earlier frame of this camera: entry e of the descending-cost order instead of wave tile e,
+          // so the few hundred expensive tiles of a frame (deep reflection chains) are dealt one to a WAVE and start first
+          // instead of piling up in the workgroups whose columns cross them
+          if (R.tile_order) first = R.tile_order[first];
           last = first + 1u;
       } else {
           // XCD x owns a list of wave tiles: without history the contiguous range [x * per, (x + 1) * per) of the
@@ -503,6 +507,9 @@ struct NraysScene {
     // (width, rows, band) geometry at a time
     uint32_t* d_tile_cost = nullptr; uint32_t* d_tile_order = nullptr; uint32_t tile_slots = 0;
     uint64_t cost_key = 0; bool cost_valid = false;
+    // analytic scenes (workgroup lists): costs are recorded on the first frame of a camera, sorted once on the second, and
+    // the order is then reused as long as the camera stays (the scene of a handle never changes)
+    uint64_t cost_cam = 0, order_key = 0, order_cam = 0; bool order_valid = false; uint32_t order_age = 0;
     uint32_t spill_entries = 0; // HBM stack entries per lane beyond the kLdsStack entries kept in LDS (0 = never needed)
     int num_cus = 256;
     int features = kFeatAll;
@@ -531,6 +538,7 @@ struct NraysScene {
     bool last_timed = true;
     int grab_override = -1;                         // NRAYS_GRAB
     bool lpt_enabled = true;                        // NRAYS_LPT=0 restores image order
+    bool lpt_analytic = false;                      // NRAYS_LPT_ANALYTIC=1: cost-ordered workgroup lists for analytic scenes (measured: no gain)
     bool cull_enabled = true;                       // NRAYS_SCREEN_CULL=0: no wave tile is decided from the scene's screen bounds
     NraysStats last;
     uint64_t last_primary = 0, last_primary_first_batch = 0;
@@ -758,6 +766,42 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
         R.tile_cost = sc->d_tile_cost;
         sc->cost_key = key; sc->cost_valid = true;
     }
+    // Analytic scenes: the same idea on the workgroup lists — measured, no gain (balls 73.8 -> 75.2 us, primitives 221 -> 229:
+    // profiles/r02_analytic_lpt.log; those frames are as long as their single most expensive tile, which already starts
+    // early enough), so it stays off unless NRAYS_LPT_ANALYTIC=1 asks for it (tools/tile_costs.py reads the recorded costs).
+    if (grab == 0u && sc->lpt_analytic && !instrumented && win_units > 0) {
+        const uint32_t nwt = lane_log2 ? win_units : win_units * 4u;
+        if (nwt > sc->tile_slots) {
+            if (sc->d_tile_cost) { (void)hipFree(sc->d_tile_cost); sc->d_tile_cost = nullptr; }
+            if (sc->d_tile_order) { (void)hipFree(sc->d_tile_order); sc->d_tile_order = nullptr; }
+            sc->tile_slots = 0; sc->cost_valid = false; sc->order_valid = false;
+            HIP_TRY(hipMalloc((void**)&sc->d_tile_cost, (size_t)nwt * sizeof(uint32_t)));
+            HIP_TRY(hipMalloc((void**)&sc->d_tile_order, (size_t)nwt * sizeof(uint32_t)));
+            sc->tile_slots = nwt;
+        }
+        const uint64_t key = (((uint64_t)p->width << 40) ^ ((uint64_t)rows << 20) ^ ((uint64_t)p->band_rows << 8) ^ ((uint64_t)p->band_owner << 4) ^ (uint64_t)R.band_owners ^ ((uint64_t)lane_log2 << 60))
+                             + 0x9E3779B97F4A7C15ull * (((uint64_t)R.win_x0 << 48) ^ ((uint64_t)R.win_nx << 32) ^ ((uint64_t)R.win_y0 << 16) ^ (uint64_t)R.win_ny);
+        uint64_t cam = 0xcbf29ce484222325ull; // FNV-1a over everything a tile's cost depends on
+        auto mix = [&](const void* q, size_t n) { const unsigned char* b = (const unsigned char*)q; for (size_t i = 0; i < n; ++i) { cam ^= b[i]; cam *= 0x100000001b3ull; } };
+        mix(p->inv_proj_view, sizeof p->inv_proj_view); mix(p->camera_eye, sizeof p->camera_eye); mix(&p->window_width, sizeof p->window_width);
+        mix(&p->ray_per_pixel, sizeof p->ray_per_pixel); mix(&p->max_depth, sizeof p->max_depth);
+        auto sort_costs = [&]() {
+            if (timed) (void)hipEventRecord(sc->ev_begin[slot], stream);
+            sc->has_prepass[slot] = true;
+            hipLaunchKernelGGL(k_tile_order, dim3(8), dim3(1024), 0, stream, sc->d_tile_cost, sc->d_tile_order, nwt);
+            sc->order_valid = true; sc->order_key = key; sc->order_cam = sc->cost_cam; sc->order_age = 0;
+        };
+        if (sc->order_valid && sc->order_key == key && sc->order_cam == cam) {
+            R.tile_order = sc->d_tile_order; // steady state of a resting camera: nothing recorded, nothing sorted
+        } else if (sc->cost_valid && sc->cost_key == key && sc->cost_cam == cam) {
+            sort_costs(); HIP_TRY(hipGetLastError()); // second frame of this camera
+            R.tile_order = sc->d_tile_order;
+        } else { // a new camera: record its costs; an order of the same geometry from a nearby camera is still a good guess
+            if (sc->cost_valid && sc->cost_key == key && (!sc->order_valid || sc->order_key != key || sc->order_age >= 8u)) { sort_costs(); HIP_TRY(hipGetLastError()); }
+            if (sc->order_valid && sc->order_key == key) { R.tile_order = sc->d_tile_order; sc->order_age++; }
+            R.tile_cost = sc->d_tile_cost; sc->cost_key = key; sc->cost_cam = cam; sc->cost_valid = true;
+        }
+    }
     bool first_primary = true;
     for (uint32_t s0 = 0; s0 < p->ray_per_pixel; s0 += batch) {
         R.sample_begin = s0; R.sample_end = std::min<uint32_t>(p->ray_per_pixel, s0 + batch);
@@ -885,6 +929,7 @@ int nrays_scene_create(const NraysSceneDesc* desc, NraysScene** out_scene) {
     if (const char* e = getenv("NRAYS_GRAB")) sc->grab_override = std::max(0, atoi(e));
     if (const char* e = getenv("NRAYS_LPT")) sc->lpt_enabled = atoi(e) != 0;
     if (const char* e = getenv("NRAYS_SCREEN_CULL")) sc->cull_enabled = atoi(e) != 0;
+    if (const char* e = getenv("NRAYS_LPT_ANALYTIC")) sc->lpt_analytic = atoi(e) != 0;
     // release bulk host copies
     std::vector<BvhNode>().swap(h.nodes); std::vector<TriRec>().swap(h.tris); std::vector<TriUv>().swap(h.triuvs);
 
@@ -977,8 +1022,8 @@ int nrays_get_stats(NraysScene* sc, NraysStats* out) {
     return NRAYS_OK;
 }
 
-#ifdef NR_PHASE_TIMING
-// Tuning builds only (tools/tile_costs.py): the per-wave-tile cycle counts (>> 4) of the last mesh frame.
+#if defined(NR_PHASE_TIMING) || defined(NR_DEBUG_TILE_COSTS)
+// Tuning builds only (tools/tile_costs.py): the per-wave-tile cycle counts (>> 4) of the last frame that recorded them.
 int nrays_debug_tile_costs(NraysScene* sc, uint32_t* out, uint32_t capacity, uint32_t* out_count) {
     if (!sc || !sc->have_last || !sc->d_tile_cost) return NRAYS_ERR_BAD_ARG;
     HIP_TRY(hipStreamSynchronize(sc->last_stream));
@@ -987,6 +1032,8 @@ int nrays_debug_tile_costs(NraysScene* sc, uint32_t* out, uint32_t capacity, uin
     *out_count = n;
     return NRAYS_OK;
 }
+#endif
+#ifdef NR_PHASE_TIMING
 // Tuning builds only (tools/phase_timing.py): wave / lane iteration counts of the node loops and the triangle loops.
 int nrays_debug_counters(NraysScene* sc, unsigned long long out[8]) {
     if (!sc || !sc->have_last) return NRAYS_ERR_BAD_ARG;
