@@ -175,7 +175,16 @@ struct DScene {
     uint32_t num_planes;
     uint32_t num_lights;
     float background[3];
+    // Small analytic scenes (no meshes; all records below within kLdsSceneBytes): one packed copy of nodes, instances,
+    // links, shading records, node AABBs, lights and plane lists, which the kFeatLdsScene kernels stage into LDS once per
+    // workgroup — a dependent record fetch then costs an LDS access instead of a trip through the vector memory path.
+    // lds_off[k] = byte offset of section k (LdsSection) inside the blob; null when the scene does not qualify.
+    const uint32_t* lds_blob;
+    uint32_t lds_bytes; // multiple of 16
+    uint32_t lds_off[10];
 };
+enum LdsSection { kLdsNodes = 0, kLdsInstances, kLdsShadowInstances, kLdsLinks, kLdsShadowLinks, kLdsShade, kLdsNodeAabbs, kLdsLights, kLdsPlanes, kLdsShadowPlanes };
+constexpr uint32_t kLdsSceneBytes = 8192;
 
 struct DRender {
     uint32_t width, height;      // full frame

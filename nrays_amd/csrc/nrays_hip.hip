@@ -110,16 +110,37 @@ __device__ __forceinline__ void flush_counters(DeviceCounters* ctr, const Cnt& c
 
 // Waves per SIMD requested per permutation (measured on MI355X, tools/kbench.py): the opaque mesh
 // kernel is latency-bound and prefers 3 waves with a few spills; the others run best at 2 without.
-constexpr int waves_per_simd(int feat) { return (feat & ~kFeatMultiSample) == kFeatMesh ? (NRAYS_WAVES_PER_SIMD > 3 ? NRAYS_WAVES_PER_SIMD : 3) : NRAYS_WAVES_PER_SIMD; }
+constexpr int waves_per_simd(int feat) { return (feat & ~(kFeatMultiSample | kFeatLdsScene)) == kFeatMesh ? (NRAYS_WAVES_PER_SIMD > 3 ? NRAYS_WAVES_PER_SIMD : 3) : NRAYS_WAVES_PER_SIMD; }
 
 template <bool STATS, int FEAT, bool PLAIN = false>
-__global__ void __launch_bounds__(kBlock, waves_per_simd(FEAT)) k_primary(DScene S, DRender R, QueueOut qo, float* __restrict__ out, DeviceCounters* ctr,
+__global__ void __launch_bounds__(kBlock, waves_per_simd(FEAT)) k_primary(DScene S0, DRender R, QueueOut qo, float* __restrict__ out, DeviceCounters* ctr,
                                                      uint32_t* spill, uint32_t tiles_x, uint32_t tiles_y, uint32_t* work_counters, uint32_t grab_arg,
                                                      uint32_t* zero_counts, DeviceCounters* zero_ctr) {
     // The scheduling path is fixed by the permutation — workgroup lists (0) for analytic-only scenes, XCD-aware HBM
     // dequeue (>= 1) for scenes with meshes — so that each kernel carries one of them; only the full-featured kernels
     // (instrumented renders, double branching) take it from the host at run time.
     const uint32_t grab = (FEAT == kFeatAll || FEAT == 15) ? grab_arg : ((FEAT & kFeatMesh) ? (grab_arg ? grab_arg : 1u) : 0u);
+    // kFeatLdsScene: the workgroup's LDS copy of the scene records (DScene::lds_blob); S then points into it, and since the
+    // traversal and shading code is inlined here the compiler sees LDS addresses and issues ds_read for every record
+    constexpr bool kLdsScene = (FEAT & kFeatLdsScene) != 0;
+    __shared__ __attribute__((aligned(16))) uint32_t lds_scene[kLdsScene ? kLdsSceneBytes / 4 : 4];
+    DScene S = S0;
+    if (kLdsScene) {
+        const __attribute__((address_space(1))) uint32_t* src = (const __attribute__((address_space(1))) uint32_t*)S0.lds_blob;
+        for (uint32_t w = threadIdx.x; w < S0.lds_bytes / 4u; w += kBlock) lds_scene[w] = src[w];
+        __syncthreads();
+        const char* lb = (const char*)lds_scene;
+        S.nodes = (const BvhNode*)(lb + S0.lds_off[kLdsNodes]);
+        S.instances = (const Instance*)(lb + S0.lds_off[kLdsInstances]);
+        S.shadow_instances = (const Instance*)(lb + S0.lds_off[kLdsShadowInstances]);
+        S.links = (const InstLink*)(lb + S0.lds_off[kLdsLinks]);
+        S.shadow_links = (const InstLink*)(lb + S0.lds_off[kLdsShadowLinks]);
+        S.shade = (const ShadeRec*)(lb + S0.lds_off[kLdsShade]);
+        S.node_aabbs = (const double*)(lb + S0.lds_off[kLdsNodeAabbs]);
+        S.lights = (const LightRec*)(lb + S0.lds_off[kLdsLights]);
+        S.planes = (const int32_t*)(lb + S0.lds_off[kLdsPlanes]);
+        S.shadow_planes = (const int32_t*)(lb + S0.lds_off[kLdsShadowPlanes]);
+    }
     __shared__ uint32_t lds_stack[kLdsStack * kBlock];
     __shared__ uint32_t block_next; // grab == 0: next entry of this workgroup's tile list
     if (grab == 0u) { // workgroup-uniform
@@ -600,6 +621,10 @@ static void launch_primary(bool instrumented, int features, uint32_t grid, hipSt
     // plain frames (tables, no RNG keys, one sample per pixel) of the analytic-only permutations
     const bool plain = R.col_tab && !R.use_rng && R.first_batch && R.sample_begin == 0u && R.sample_end == 1u;
 #define NR_LAUNCH_PLAIN(F) hipLaunchKernelGGL((k_primary<false, F, true>), dim3(grid), dim3(kBlock), 0, stream, d, R, qo, out, ctr, spill, tx, ty, work, grab, zero_counts, zero_ctr)
+    if (plain && features == 33) { NR_LAUNCH_PLAIN(33); return; }
+    if (plain && features == 37) { NR_LAUNCH_PLAIN(37); return; }
+    if (plain && features == 49) { NR_LAUNCH_PLAIN(49); return; }
+    if (plain && features == 53) { NR_LAUNCH_PLAIN(53); return; }
     if (plain && features == 1) { NR_LAUNCH_PLAIN(1); return; }
     if (plain && features == 5) { NR_LAUNCH_PLAIN(5); return; }
     if (plain && features == 17) { NR_LAUNCH_PLAIN(17); return; }
@@ -610,6 +635,10 @@ static void launch_primary(bool instrumented, int features, uint32_t grid, hipSt
     if (plain && features == 22) { NR_LAUNCH_PLAIN(22); return; }
 #undef NR_LAUNCH_PLAIN
     switch (features) { // bit 8 (double branching) only in the full kernels; bit 16 = multi-sample lighting
+    case 33: NR_LAUNCH(33); break; // 1, 5, 17, 21 with the scene records in LDS
+    case 37: NR_LAUNCH(37); break;
+    case 49: NR_LAUNCH(49); break;
+    case 53: NR_LAUNCH(53); break;
     case 1: NR_LAUNCH(1); break;
     case 2: NR_LAUNCH(2); break;
     case 3: NR_LAUNCH(3); break;
@@ -923,6 +952,38 @@ int nrays_scene_create(const NraysSceneDesc* desc, NraysScene** out_scene) {
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, sc->device) == hipSuccess && cus > 0) sc->num_cus = cus;
     }
     sc->features = h.features ? h.features : kFeatAll;
+    // small analytic scenes: one packed copy of the records for the kernels that read them from LDS (DScene::lds_blob)
+    sc->d.lds_blob = nullptr; sc->d.lds_bytes = 0;
+    { const char* e = getenv("NRAYS_LDS_SCENE");
+      const int f = sc->features;
+      if ((f == 1 || f == 5 || f == 17 || f == 21) && !(e && atoi(e) == 0)) {
+        std::vector<uint8_t> blob;
+        auto section = [&](int k, const void* q, size_t n) { // 16-byte aligned sections
+            blob.resize((blob.size() + 15u) & ~(size_t)15u);
+            sc->d.lds_off[k] = (uint32_t)blob.size();
+            const uint8_t* b = (const uint8_t*)q;
+            blob.insert(blob.end(), b, b + n);
+        };
+        section(kLdsNodes, h.nodes.data(), h.nodes.size() * sizeof(BvhNode));
+        section(kLdsInstances, h.instances.data(), h.instances.size() * sizeof(Instance));
+        section(kLdsShadowInstances, h.shadow_instances.data(), h.shadow_instances.size() * sizeof(Instance));
+        section(kLdsLinks, h.links.data(), h.links.size() * sizeof(InstLink));
+        section(kLdsShadowLinks, h.shadow_links.data(), h.shadow_links.size() * sizeof(InstLink));
+        section(kLdsShade, h.shade.data(), h.shade.size() * sizeof(ShadeRec));
+        section(kLdsNodeAabbs, h.node_aabbs.data(), h.node_aabbs.size() * sizeof(double));
+        section(kLdsLights, h.lights.data(), h.lights.size() * sizeof(LightRec));
+        section(kLdsPlanes, h.planes.data(), h.planes.size() * sizeof(int32_t));
+        section(kLdsShadowPlanes, h.shadow_planes.data(), h.shadow_planes.size() * sizeof(int32_t));
+        blob.resize((blob.size() + 15u) & ~(size_t)15u);
+        if (!blob.empty() && blob.size() <= kLdsSceneBytes) {
+            std::vector<uint32_t> words(blob.size() / 4);
+            std::memcpy(words.data(), blob.data(), blob.size());
+            if ((rc = upload(sc, words, &sc->d.lds_blob)) != NRAYS_OK) return bail(rc);
+            sc->d.lds_bytes = (uint32_t)blob.size();
+            sc->features |= kFeatLdsScene;
+        }
+      }
+    }
     if (const char* e = getenv("NRAYS_MAX_PRIMARY")) { sc->max_primary_per_launch = (uint64_t)std::max(1ll, atoll(e)); sc->max_primary_forced = true; }
     if (const char* e = getenv("NRAYS_LANE_LOG2")) sc->lane_log2_override = std::max(0, std::min(6, atoi(e)));
     if (const char* e = getenv("NRAYS_EVENT_STRIDE")) sc->event_stride = (uint32_t)std::max(1, atoi(e));

@@ -42,7 +42,8 @@ enum Features : int {
     kFeatDouble = 8,       // some node can spawn a reflection AND a refraction at one hit (second child -> HBM queue)
     kFeatMultiSample = 16, // more than one light sample per hit: shadow rays are traced inside the light loop;
                            // otherwise the single shadow ray is traced before the shading state exists
-    kFeatAll = 31
+    kFeatAll = 31,
+    kFeatLdsScene = 32     // analytic-only scenes whose records fit DScene::lds_blob: the kernel reads them from LDS
 };
 
 // ---------------------------------------------------------------- vector algebra (f64) -------
@@ -441,9 +442,11 @@ NR_DEV void load_xform(const Instance& in, Xform& m) {
 // would live in scratch memory and cost a store + load round trip per call.
 // The instance comes as an explicitly GLOBAL pointer: across the call boundary a plain reference is a generic pointer
 // and every field read a flat_load.
-typedef const __attribute__((address_space(1))) Instance* GInstance;
-__device__ __noinline__ Isect cast_analytic(GInstance inp, d3 o, d3 d) {
-    const __attribute__((address_space(1))) Instance& in = *inp;
+typedef const __attribute__((address_space(1))) Instance* GInstance; // instance record in global memory
+typedef const __attribute__((address_space(3))) Instance* LInstance; // instance record in LDS (kFeatLdsScene kernels)
+template <class P>
+__device__ __forceinline__ Isect cast_analytic_at(P inp, d3 o, d3 d) {
+    const auto& in = *inp;
     bool solid = (in.flags & kInstSolid) != 0;
     Xform m;
 #pragma unroll
@@ -461,6 +464,14 @@ __device__ __noinline__ Isect cast_analytic(GInstance inp, d3 o, d3 d) {
     default: break;
     }
     return out;
+}
+__device__ __noinline__ Isect cast_analytic(GInstance inp, d3 o, d3 d) { return cast_analytic_at(inp, o, d); }
+__device__ __noinline__ Isect cast_analytic_lds(LInstance inp, d3 o, d3 d) { return cast_analytic_at(inp, o, d); }
+// The instance records of a kFeatLdsScene kernel live in the workgroup's LDS copy of the scene (k_primary).
+template <int FEAT>
+NR_DEV Isect cast_instance(const Instance& in, d3 o, d3 d) {
+    if (FEAT & kFeatLdsScene) return cast_analytic_lds((LInstance)&in, o, d);
+    return cast_analytic((GInstance)&in, o, d);
 }
 
 // ---------------------------------------------------------------- textures & materials -------
@@ -720,7 +731,7 @@ template <bool SHADOW, int FEAT, bool CHECK = false>
 NR_DEV bool resolve_hit(const DScene& S, d3 o, d3 d, const Hit& h, Isect& out, uint32_t& node_id) {
     const Instance& in = (SHADOW ? S.shadow_instances : S.instances)[h.inst];
     if ((FEAT & kFeatAnalytic) && (!(FEAT & kFeatMesh) || in.kind != NRAYS_SHAPE_TRIMESH)) {
-        out = cast_analytic((GInstance)&in, o, d);
+        out = cast_instance<FEAT>(in, o, d);
         node_id = (uint32_t)in.node_id;
         return !CHECK || in.kind == NRAYS_SHAPE_PLANE || node_aabb_pass(S, node_id, o, d);
     }
@@ -933,7 +944,7 @@ NR_DEV bool traverse(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, Hit&
         if (kAnalytic) { // TLAS leaf: an analytic shape (or a plane pseudo-leaf)
             const Instance& in = insts[first];
             if (STATS) cnt.prim++;
-            Isect is = cast_analytic((GInstance)&in, o, d);
+            Isect is = cast_instance<FEAT>(in, o, d);
             if (is.hit && (!GATED || in.kind == NRAYS_SHAPE_PLANE || node_aabb_pass(S, (uint32_t)in.node_id, o, d))) {
                 if (SHADOW) {
                     if (is.toi <= tlimit) {
