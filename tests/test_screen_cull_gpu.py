@@ -117,3 +117,24 @@ def test_degenerate_cameras_fall_back_to_every_pixel(gpu, monkeypatch):
     ib, _ = _render(b, p)
     assert np.array_equal(ia, ib)
     assert not math.isnan(float(ia.sum()))
+
+
+@pytest.mark.parametrize("make", [su.balls_scene, lambda: su.primitives_scene(0.0, 1), lambda: su.primitives_scene(0.1, 10),
+                                  lambda: su.random_shapes_scene(5, n=6, with_mesh=False)], ids=["balls", "primitives", "primitives area light", "random shapes"])
+def test_scene_records_in_lds_do_not_change_a_frame(gpu, monkeypatch, make):
+    """Small analytic scenes are rendered by kernels that read nodes / instances / shading records from an LDS copy
+    (DScene::lds_blob); NRAYS_LDS_SCENE=0 keeps a handle on the kernels that read them from HBM.  Same pixels, same rays."""
+    monkeypatch.delenv("NRAYS_LDS_SCENE", raising=False)
+    a, cam = make()
+    a.device_handle()
+    monkeypatch.setenv("NRAYS_LDS_SCENE", "0")
+    b, _ = make()
+    b.device_handle()
+    monkeypatch.delenv("NRAYS_LDS_SCENE", raising=False)
+    for kw in (dict(), dict(spp=4, window=1.0, seed=3)):
+        p, _ = su.camera_params(cam, 320, 200, **kw)
+        ia, sa = _render(a, p)
+        ib, sb = _render(b, p)
+        assert np.array_equal(ia, ib)
+        for k in CLASSES:
+            assert getattr(sa, k) == getattr(sb, k), k
