@@ -372,13 +372,22 @@ __device__ __forceinline__ uint32_t cost_bucket(uint32_t c) {
     uint32_t m = e >= 3u ? (c >> (e - 3u)) & 7u : (c << (3u - e)) & 7u;
     return e * 8u + m;
 }
-__global__ void __launch_bounds__(1024) k_tile_order(const uint32_t* __restrict__ cost, uint32_t* __restrict__ order, uint32_t n) {
+__global__ void __launch_bounds__(1024) k_tile_order(const uint32_t* __restrict__ cost, uint32_t* __restrict__ order, uint32_t n, unsigned long long* stats) {
     __shared__ uint32_t hist[256];
+    __shared__ unsigned long long wg_sum;
+    __shared__ uint32_t wg_max;
     const uint32_t x = blockIdx.x; // 0..7
     if (threadIdx.x < 256u) hist[threadIdx.x] = 0u;
+    if (threadIdx.x == 0u) { wg_sum = 0ULL; wg_max = 0u; }
     __syncthreads();
-    for (uint32_t i = x + 8u * threadIdx.x; i < n; i += 8u * 1024u) atomicAdd(&hist[cost_bucket(cost[i])], 1u);
+    unsigned long long my_sum = 0ULL; uint32_t my_max = 0u;
+    for (uint32_t i = x + 8u * threadIdx.x; i < n; i += 8u * 1024u) { const uint32_t c = cost[i]; atomicAdd(&hist[cost_bucket(c)], 1u); my_sum += c; my_max = c > my_max ? c : my_max; }
+    if (stats) { // stats[0] = sum of all tile costs, stats[1] = the largest one (both in the 16-cycle units of the cost array)
+        if (my_sum) atomicAdd(&wg_sum, my_sum);
+        if (my_max) atomicMax(&wg_max, my_max);
+    }
     __syncthreads();
+    if (stats && threadIdx.x == 0u) { atomicAdd(&stats[0], wg_sum); atomicMax(&stats[1], (unsigned long long)wg_max); }
     if (threadIdx.x == 0) { // exclusive prefix, most expensive bucket first
         uint32_t acc = 0u;
         for (int b = 255; b >= 0; --b) { uint32_t c = hist[b]; hist[b] = acc; acc += c; }
@@ -531,6 +540,11 @@ struct NraysScene {
     // analytic scenes (workgroup lists): costs are recorded on the first frame of a camera, sorted once on the second, and
     // the order is then reused as long as the camera stays (the scene of a handle never changes)
     uint64_t cost_cam = 0, order_key = 0, order_cam = 0; bool order_valid = false; uint32_t order_age = 0;
+    // ... and the sort also reports the sum and the maximum of the costs: their ratio is the frame's parallelism, which
+    // decides between cost-ordered lists on ONE workgroup per CU (few long tiles: a wave alone on its SIMD finishes a
+    // deep reflection chain sooner) and image-order lists on two (many tiles: throughput)
+    unsigned long long* d_cost_stats = nullptr; unsigned long long* h_cost_stats = nullptr; hipEvent_t ev_stats = nullptr;
+    bool stats_pending = false, lone_waves = false;
     uint32_t spill_entries = 0; // HBM stack entries per lane beyond the kLdsStack entries kept in LDS (0 = never needed)
     int num_cus = 256;
     int features = kFeatAll;
@@ -559,7 +573,8 @@ struct NraysScene {
     bool last_timed = true;
     int grab_override = -1;                         // NRAYS_GRAB
     bool lpt_enabled = true;                        // NRAYS_LPT=0 restores image order
-    bool lpt_analytic = false;                      // NRAYS_LPT_ANALYTIC=1: cost-ordered workgroup lists for analytic scenes (measured: no gain)
+    bool lpt_analytic = true;                       // NRAYS_LPT_ANALYTIC=0: analytic scenes never switch to cost-ordered lists on one workgroup per CU
+    int grid_wg_per_cu = 0;                         // NRAYS_GRID_WG_PER_CU=n caps the persistent grid at n workgroups per CU (tuning)
     bool cull_enabled = true;                       // NRAYS_SCREEN_CULL=0: no wave tile is decided from the scene's screen bounds
     NraysStats last;
     uint64_t last_primary = 0, last_primary_first_batch = 0;
@@ -731,9 +746,7 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
     // persistent grid: exactly the workgroups that can be resident (one 4-wave workgroup per CU per wave/SIMD)
     uint32_t grid_primary = std::min<uint32_t>(std::min<uint32_t>(((ntiles + 7u) / 8u) * 8u, (uint32_t)kMaxGrid),
                                                      (uint32_t)sc->num_cus * (uint32_t)waves_per_simd(instrumented ? kFeatAll : sc->features) * 256u / (uint32_t)kBlock);
-#ifdef NR_PHASE_TIMING
-    if (const char* e = getenv("NRAYS_GRID_WG_PER_CU")) grid_primary = std::min<uint32_t>(grid_primary, (uint32_t)sc->num_cus * (uint32_t)std::max(1, atoi(e))); // tuning builds: occupancy sensitivity
-#endif
+    if (sc->grid_wg_per_cu > 0) grid_primary = std::min<uint32_t>(grid_primary, (uint32_t)sc->num_cus * (uint32_t)sc->grid_wg_per_cu); // NRAYS_GRID_WG_PER_CU: occupancy sensitivity runs
 
     // All per-handle state (double-buffered counters, queues, raygen tables, tile costs) assumes that the renders of one
     // handle execute one after the other: a render on a different stream than its predecessor is ordered behind it.
@@ -787,7 +800,7 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
         if (sc->cost_valid && sc->cost_key == key) {
             if (timed) HIP_TRY(hipEventRecord(sc->ev_begin[slot], stream));
             sc->has_prepass[slot] = true;
-            hipLaunchKernelGGL(k_tile_order, dim3(8), dim3(1024), 0, stream, sc->d_tile_cost, sc->d_tile_order, nwt);
+            hipLaunchKernelGGL(k_tile_order, dim3(8), dim3(1024), 0, stream, sc->d_tile_cost, sc->d_tile_order, nwt, (unsigned long long*)nullptr);
             HIP_TRY(hipGetLastError());
             R.tile_order = sc->d_tile_order;
             grab = 1u;
@@ -795,9 +808,12 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
         R.tile_cost = sc->d_tile_cost;
         sc->cost_key = key; sc->cost_valid = true;
     }
-    // Analytic scenes: the same idea on the workgroup lists — measured, no gain (balls 73.8 -> 75.2 us, primitives 221 -> 229:
-    // profiles/r02_analytic_lpt.log; those frames are as long as their single most expensive tile, which already starts
-    // early enough), so it stays off unless NRAYS_LPT_ANALYTIC=1 asks for it (tools/tile_costs.py reads the recorded costs).
+    // Analytic scenes (workgroup lists): the frames are a few hundred long tiles (deep reflection chains, ~10^5 cycles each) among
+    // thousands of short ones, and a long tile runs ~1.5x faster when its wave has the SIMD to itself.  The first frame of a
+    // camera records the tile costs, the second sorts them (k_tile_order) and reads back their sum and maximum; when the frame's
+    // parallelism sum / max is below ~1.5 waves per SIMD of the chip, the following frames of that camera deal the tiles in
+    // descending cost order to ONE workgroup per CU — otherwise image order on two, as before (profiles/r02_analytic_lpt.log:
+    // balls 71.1 -> 61.2 us; primitives, whose every tile is long, 202 us with two workgroups against 293 with one).
     if (grab == 0u && sc->lpt_analytic && !instrumented && win_units > 0) {
         const uint32_t nwt = lane_log2 ? win_units : win_units * 4u;
         if (nwt > sc->tile_slots) {
@@ -808,27 +824,47 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
             HIP_TRY(hipMalloc((void**)&sc->d_tile_order, (size_t)nwt * sizeof(uint32_t)));
             sc->tile_slots = nwt;
         }
+        if (!sc->d_cost_stats) {
+            HIP_TRY(hipMalloc((void**)&sc->d_cost_stats, 2 * sizeof(unsigned long long)));
+            HIP_TRY(hipHostMalloc((void**)&sc->h_cost_stats, 2 * sizeof(unsigned long long), hipHostMallocDefault));
+            HIP_TRY(hipEventCreateWithFlags(&sc->ev_stats, hipEventDisableTiming));
+        }
         const uint64_t key = (((uint64_t)p->width << 40) ^ ((uint64_t)rows << 20) ^ ((uint64_t)p->band_rows << 8) ^ ((uint64_t)p->band_owner << 4) ^ (uint64_t)R.band_owners ^ ((uint64_t)lane_log2 << 60))
                              + 0x9E3779B97F4A7C15ull * (((uint64_t)R.win_x0 << 48) ^ ((uint64_t)R.win_nx << 32) ^ ((uint64_t)R.win_y0 << 16) ^ (uint64_t)R.win_ny);
         uint64_t cam = 0xcbf29ce484222325ull; // FNV-1a over everything a tile's cost depends on
         auto mix = [&](const void* q, size_t n) { const unsigned char* b = (const unsigned char*)q; for (size_t i = 0; i < n; ++i) { cam ^= b[i]; cam *= 0x100000001b3ull; } };
         mix(p->inv_proj_view, sizeof p->inv_proj_view); mix(p->camera_eye, sizeof p->camera_eye); mix(&p->window_width, sizeof p->window_width);
         mix(&p->ray_per_pixel, sizeof p->ray_per_pixel); mix(&p->max_depth, sizeof p->max_depth);
-        auto sort_costs = [&]() {
-            if (timed) (void)hipEventRecord(sc->ev_begin[slot], stream);
+        if (sc->stats_pending && hipEventQuery(sc->ev_stats) == hipSuccess) { // the sum / maximum of the last sort have arrived
+            const double sum = (double)sc->h_cost_stats[0], mx = (double)sc->h_cost_stats[1];
+            sc->lone_waves = mx > 0.0 && sum / mx < 1.5 * 4.0 * (double)sc->num_cus;
+            sc->stats_pending = false;
+        }
+        auto sort_costs = [&]() -> int {
+            if (sc->stats_pending) HIP_TRY(hipEventSynchronize(sc->ev_stats)); // (a camera that changes every few frames: the previous read-back is long done)
+            if (timed) HIP_TRY(hipEventRecord(sc->ev_begin[slot], stream));
             sc->has_prepass[slot] = true;
-            hipLaunchKernelGGL(k_tile_order, dim3(8), dim3(1024), 0, stream, sc->d_tile_cost, sc->d_tile_order, nwt);
+            HIP_TRY(hipMemsetAsync(sc->d_cost_stats, 0, 2 * sizeof(unsigned long long), stream));
+            hipLaunchKernelGGL(k_tile_order, dim3(8), dim3(1024), 0, stream, sc->d_tile_cost, sc->d_tile_order, nwt, sc->d_cost_stats);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(sc->h_cost_stats, sc->d_cost_stats, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipEventRecord(sc->ev_stats, stream));
+            sc->stats_pending = true;
             sc->order_valid = true; sc->order_key = key; sc->order_cam = sc->cost_cam; sc->order_age = 0;
+            return NRAYS_OK;
         };
         if (sc->order_valid && sc->order_key == key && sc->order_cam == cam) {
-            R.tile_order = sc->d_tile_order; // steady state of a resting camera: nothing recorded, nothing sorted
+            // steady state of a resting camera: nothing recorded, nothing sorted
         } else if (sc->cost_valid && sc->cost_key == key && sc->cost_cam == cam) {
-            sort_costs(); HIP_TRY(hipGetLastError()); // second frame of this camera
-            R.tile_order = sc->d_tile_order;
-        } else { // a new camera: record its costs; an order of the same geometry from a nearby camera is still a good guess
-            if (sc->cost_valid && sc->cost_key == key && (!sc->order_valid || sc->order_key != key || sc->order_age >= 8u)) { sort_costs(); HIP_TRY(hipGetLastError()); }
-            if (sc->order_valid && sc->order_key == key) { R.tile_order = sc->d_tile_order; sc->order_age++; }
+            const int rc = sort_costs(); if (rc != NRAYS_OK) return rc; // second frame of this camera
+        } else { // a new camera: record its costs; the order of a nearby camera of the same geometry is still a good guess
+            if (sc->cost_valid && sc->cost_key == key && (!sc->order_valid || sc->order_key != key || sc->order_age >= 8u)) { const int rc = sort_costs(); if (rc != NRAYS_OK) return rc; }
+            if (sc->order_valid && sc->order_key == key) sc->order_age++;
             R.tile_cost = sc->d_tile_cost; sc->cost_key = key; sc->cost_cam = cam; sc->cost_valid = true;
+        }
+        if (sc->order_valid && sc->order_key == key && sc->lone_waves && !sc->stats_pending) {
+            R.tile_order = sc->d_tile_order;
+            grid_primary = std::min<uint32_t>(grid_primary, (uint32_t)sc->num_cus);
         }
     }
     bool first_primary = true;
@@ -991,6 +1027,7 @@ int nrays_scene_create(const NraysSceneDesc* desc, NraysScene** out_scene) {
     if (const char* e = getenv("NRAYS_LPT")) sc->lpt_enabled = atoi(e) != 0;
     if (const char* e = getenv("NRAYS_SCREEN_CULL")) sc->cull_enabled = atoi(e) != 0;
     if (const char* e = getenv("NRAYS_LPT_ANALYTIC")) sc->lpt_analytic = atoi(e) != 0;
+    if (const char* e = getenv("NRAYS_GRID_WG_PER_CU")) sc->grid_wg_per_cu = std::max(0, atoi(e));
     // release bulk host copies
     std::vector<BvhNode>().swap(h.nodes); std::vector<TriRec>().swap(h.tris); std::vector<TriUv>().swap(h.triuvs);
 
@@ -1029,6 +1066,9 @@ void nrays_scene_destroy(NraysScene* sc) {
     if (sc->d_tables) (void)hipFree(sc->d_tables);
     if (sc->d_tile_cost) (void)hipFree(sc->d_tile_cost);
     if (sc->d_tile_order) (void)hipFree(sc->d_tile_order);
+    if (sc->d_cost_stats) (void)hipFree(sc->d_cost_stats);
+    if (sc->h_cost_stats) (void)hipHostFree(sc->h_cost_stats);
+    if (sc->ev_stats) (void)hipEventDestroy(sc->ev_stats);
     if (sc->d_counters_primary) (void)hipFree(sc->d_counters_primary);
     for (int k = 0; k < NraysScene::kRing; ++k) {
         if (sc->ev_begin[k]) (void)hipEventDestroy(sc->ev_begin[k]);
