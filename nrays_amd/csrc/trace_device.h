@@ -482,7 +482,12 @@ NR_DEV f4 tex_at(const ShadeTex& t, uint32_t x, uint32_t y) {
     // pointer loaded from memory makes every fetch a flat_load)
     if ((t.mode & 0xffu) == NRAYS_TEXEL_RGBA8) {
         const uint32_t p = ((const __attribute__((address_space(1))) uint32_t*)t.texels)[i]; // r | g << 8 | b << 16 | a << 24
-        r.x = (float)(p & 0xffu) / 255.0f; r.y = (float)((p >> 8) & 0xffu) / 255.0f; r.z = (float)((p >> 16) & 0xffu) / 255.0f; r.w = (float)(p >> 24) / 255.0f;
+        // `u8 as f32 / 255.0` (texture2d.rs:111-162) without the ten-instruction IEEE f32 division: for every byte value the
+        // f64 product x * (1 / 255), rounded to f32, IS the correctly rounded f32 quotient (all 256 cases are compared in
+        // tests/test_numerics_tables.py; the plain f32 product x * fl(1 / 255) is wrong for 126 of them)
+        const double k = 1.0 / 255.0;
+        r.x = (float)((double)(p & 0xffu) * k); r.y = (float)((double)((p >> 8) & 0xffu) * k);
+        r.z = (float)((double)((p >> 16) & 0xffu) * k); r.w = (float)((double)(p >> 24) * k);
     } else {
         const __attribute__((address_space(1))) float* p = (const __attribute__((address_space(1))) float*)t.texels + 4 * i;
         r.x = p[0]; r.y = p[1]; r.z = p[2]; r.w = p[3];
