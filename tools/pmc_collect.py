@@ -39,7 +39,7 @@ def rocprofv3_path():
     return shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
 
 
-def collect(scene, passes=None, steps=3, kernel_filter="k_primary<false", width=1920, height=1080, timeout=300, keep_dir=None):
+def collect(scene, passes=None, steps=12, kernel_filter="k_primary<false", width=1920, height=1080, timeout=300, keep_dir=None):
     """Returns {counter: mean per launch of the primary kernel, ..., 'launches': n, 'errors': [...]}."""
     rp = rocprofv3_path()
     res = {"scene": scene, "kernel_filter": kernel_filter, "resolution": [width, height], "errors": []}
@@ -85,7 +85,7 @@ def collect(scene, passes=None, steps=3, kernel_filter="k_primary<false", width=
 if __name__ == "__main__":
     scene, out = sys.argv[1], sys.argv[2]
     kern = sys.argv[3] if len(sys.argv) > 3 else "k_primary<false"
-    r = collect(scene, kernel_filter=kern, steps=5)
+    r = collect(scene, kernel_filter=kern)
     r["command"] = "python tools/pmc_collect.py %s %s" % (scene, out)
     try:
         r["git_head"] = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
