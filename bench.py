@@ -77,8 +77,10 @@ def roofline_block(pk, tst, W, owned_rows, scene_bytes, pmc, pmc_source):
          "units_per_launch": {"rays": int(pk.total_rays()), "node_tests": int(pk.node_tests), "tri_tests": int(pk.tri_tests),
                               "prim_tests": int(pk.prim_tests), "hit_records": int(pk.hit_records), "tex_samples": int(pk.tex_samples)},
          "note": "frac = algorithmic record bytes (SURVEY 8d formula, AABB tests counted per existing child box) / kernel time / "
-                 "HBM peak: a rate of useful bytes, NOT a DRAM utilisation — the scene is cache-resident, see dram_frac; the "
-                 "kernel is bound by VALU issue x SIMD divergence (valu_active_frac, DESIGN.md 5)"}
+                 "HBM peak: a rate of useful bytes, NOT a DRAM utilisation — the scene is cache-resident, see dram_frac. Tiles the "
+                 "scene's screen bounds decide cost no box test, so culling LOWERS this fraction while the frame gets faster. What "
+                 "bounds the kernel (DESIGN.md 5): analytic frames the latency of their longest tile's dependent chain, mesh frames "
+                 "VALU issue of the node loop at two waves per SIMD (valu_active_frac)"}
     if pmc and t > 0:
         r["traffic_source"] = pmc_source
         if pmc.get("hbm_bytes_per_launch") is not None:
