@@ -138,3 +138,28 @@ def test_scene_records_in_lds_do_not_change_a_frame(gpu, monkeypatch, make):
         assert np.array_equal(ia, ib)
         for k in CLASSES:
             assert getattr(sa, k) == getattr(sb, k), k
+
+
+@pytest.mark.parametrize("make", [su.balls_scene, lambda: su.primitives_scene(0.0, 1), lambda: su.mesh_scene()], ids=["balls", "primitives", "mesh"])
+def test_repeated_frames_of_a_resting_camera_are_identical(gpu, make):
+    """A handle settles its per-camera scheduling state over the first frames of a camera (tile costs recorded, sorted, then —
+    for frames that are a handful of long tiles — cost-ordered work lists on one workgroup per CU; mesh scenes re-sort every
+    frame).  None of it may change a pixel or a ray count: six frames of one camera, a second camera in between, all equal to
+    what a fresh handle renders first."""
+    a, cam = make()
+    other = dict(cam, eye=(cam["eye"][0] + 1.5, cam["eye"][1] + 0.5, cam["eye"][2]))
+    p, _ = su.camera_params(cam, 512, 288)
+    q, _ = su.camera_params(other, 512, 288)
+    first, s0 = _render(a, p)
+    for k in range(6):
+        img, st = _render(a, p)
+        assert np.array_equal(img, first), k
+        for c in CLASSES:
+            assert getattr(st, c) == getattr(s0, c), (k, c)
+        if k == 3:  # a different camera in between: its own costs, the stale order of the first
+            fresh, _ = make()
+            want, _ = _render(fresh, q)
+            got, _ = _render(a, q)
+            assert np.array_equal(got, want)
+    ref, ost = oracle.render(a.descriptor, p, 8)
+    assert np.abs(first - ref).max() <= 1e-4
