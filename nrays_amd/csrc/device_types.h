@@ -205,6 +205,10 @@ struct DRender {
     // work lists; the pixels of all other blocks are filled with the background by the kernel's prologue.  Equal to the
     // whole frame when nothing can be decided (or when the frame is rendered in several sample batches).
     uint32_t win_x0, win_nx, win_y0, win_ny;
+    // Cost-ordered workgroup lists (tile_order != null, analytic scenes): the first lead_wgs workgroups — one per CU —
+    // own the 4 * lead_wgs most expensive entries, one per wave, so every long tile starts at once on a SIMD of its own;
+    // the remaining entries (and the rows outside the window) are dealt to ALL workgroups.  0 = one uniform list.
+    uint32_t lead_wgs;
     double window_width;
     double eye[3];
     double m[16];                // (P V)^-1 column-major
@@ -217,6 +221,9 @@ struct DRender {
     // Mesh scenes (dynamic dequeue): per-wave-tile cost of this frame (written) and the wave tiles in
     // descending order of the previous frame's cost (read; null = image order).  Scheduling only.
     uint32_t* tile_cost;
+#ifdef NR_DEBUG_TILE_COSTS
+    uint32_t* wave_times; // tuning builds: per wave {kernel entry, first tile, exit} in 10 ns ticks (s_memrealtime) and its tile count
+#endif
     const uint32_t* tile_order;
 };
 

@@ -110,7 +110,32 @@ __device__ __forceinline__ void flush_counters(DeviceCounters* ctr, const Cnt& c
 
 // Waves per SIMD requested per permutation (measured on MI355X, tools/kbench.py): the opaque mesh
 // kernel is latency-bound and prefers 3 waves with a few spills; the others run best at 2 without.
-constexpr int waves_per_simd(int feat) { return (feat & ~(kFeatMultiSample | kFeatLdsScene)) == kFeatMesh ? (NRAYS_WAVES_PER_SIMD > 3 ? NRAYS_WAVES_PER_SIMD : 3) : NRAYS_WAVES_PER_SIMD; }
+#ifndef NR_OPAQUE_MESH_WAVES
+#define NR_OPAQUE_MESH_WAVES 3
+#endif
+constexpr int waves_per_simd(int feat) { return (feat & ~(kFeatMultiSample | kFeatLdsScene)) == kFeatMesh ? (NRAYS_WAVES_PER_SIMD > NR_OPAQUE_MESH_WAVES ? NRAYS_WAVES_PER_SIMD : NR_OPAQUE_MESH_WAVES) : NRAYS_WAVES_PER_SIMD; }
+
+// One row of the compact frame buffer outside the window of blocks that can see the scene (k_primary): background sums
+// (padding rows of the last band: zero) for the floats t0, t0 + tstep, ... of the row.  Out of line: its registers and
+// uniforms stay out of the tile loop's allocation.
+__device__ __noinline__ void fill_background_row(float bg0, float bg1, float bg2, uint32_t spp, float* out, uint32_t width, uint32_t height,
+                                                 uint32_t band_rows, uint32_t band_owner, uint32_t band_owners, uint32_t win_x0, uint32_t win_nx,
+                                                 uint32_t win_y0, uint32_t win_ny, uint32_t lane_log2, uint32_t rl, uint32_t t0, uint32_t tstep) {
+    const uint32_t bwl = lane_log2 ? (7u - lane_log2) >> 1 : 4u, bhl = lane_log2 ? (6u - lane_log2) >> 1 : 4u;
+    const uint32_t wi0 = win_x0 << bwl, wi1 = (win_x0 + win_nx) << bwl, wr0 = win_y0 << bhl, wr1 = (win_y0 + win_ny) << bhl;
+    float b0 = 0.0f, b1 = 0.0f, b2 = 0.0f;
+    for (uint32_t s = 0; s < spp; ++s) { b0 = b0 + bg0; b1 = b1 + bg1; b2 = b2 + bg2; }
+    uint32_t j = rl;
+    if (band_rows != 0 && band_owners > 1) j = ((rl / band_rows) * band_owners + band_owner) * band_rows + (rl % band_rows);
+    const bool real = j < height;
+    const bool split = rl >= wr0 && rl < wr1 && win_nx != 0u; // this row crosses the window: skip its columns
+    __attribute__((address_space(1))) float* row = (__attribute__((address_space(1))) float*)(out + (size_t)rl * width * 3);
+    for (uint32_t f = t0; f < width * 3u; f += tstep) {
+        const uint32_t i = f / 3u, c = f - i * 3u;
+        if (split && i >= wi0 && i < wi1) continue;
+        row[f] = real ? (c == 0u ? b0 : (c == 1u ? b1 : b2)) : 0.0f;
+    }
+}
 
 template <bool STATS, int FEAT, bool PLAIN = false>
 __global__ void __launch_bounds__(kBlock, waves_per_simd(FEAT)) k_primary(DScene S0, DRender R, QueueOut qo, float* __restrict__ out, DeviceCounters* ctr,
@@ -166,6 +191,10 @@ __global__ void __launch_bounds__(kBlock, waves_per_simd(FEAT)) k_primary(DScene
 #endif
 
     const uint32_t lane = threadIdx.x & 63u;
+#ifdef NR_DEBUG_TILE_COSTS
+    const uint32_t dbg_t_entry = (uint32_t)__builtin_amdgcn_s_memrealtime();
+    uint32_t dbg_t_first = 0u, dbg_tiles = 0u;
+#endif
     // Sample-major lane mapping of anti-aliased frames (ray_per_pixel >= 2): 2^lane_log2 lanes share ONE pixel and trace
     // its samples side by side, so a wave covers 64 >> lane_log2 pixels (8x4, 4x4, 4x2, 2x2, 2x1, 1x1) instead of 8x8 and
     // its 64 rays start within a few pixels of each other — the coherence that thin geometry (hair: 16 % SIMD efficiency
@@ -175,27 +204,19 @@ __global__ void __launch_bounds__(kBlock, waves_per_simd(FEAT)) k_primary(DScene
     const uint32_t lane_log2 = PLAIN ? 0u : R.lane_log2;
     const uint32_t nwt = lane_log2 ? R.win_nx * R.win_ny : R.win_nx * R.win_ny * 4u; // wave tiles of the window (device_types.h: DRender::win_*)
 
-    // Prologue: the pixels outside the window cannot be reached by the scene (screen_bounds()): every sample returns the
-    // background, the pixel holds their f32 sum in sample order (padding rows of the last band: zero).  Rows are dealt
-    // round-robin to the workgroups; the window's own pixels are written by the tiles below, so no pixel has two writers.
-    if (R.win_nx < tiles_x || R.win_ny < tiles_y) {
-        const uint32_t bwl = lane_log2 ? (7u - lane_log2) >> 1 : 4u, bhl = lane_log2 ? (6u - lane_log2) >> 1 : 4u;
-        const uint32_t wi0 = R.win_x0 << bwl, wi1 = (R.win_x0 + R.win_nx) << bwl, wr0 = R.win_y0 << bhl, wr1 = (R.win_y0 + R.win_ny) << bhl;
-        float b0 = 0.0f, b1 = 0.0f, b2 = 0.0f;
-        for (uint32_t s = 0; s < R.spp; ++s) { b0 = b0 + S.background[0]; b1 = b1 + S.background[1]; b2 = b2 + S.background[2]; }
-        for (uint32_t rl = blockIdx.x; rl < R.rows_local; rl += gridDim.x) {
-            uint32_t j = rl;
-            if (R.band_rows != 0 && R.band_owners > 1) j = ((rl / R.band_rows) * R.band_owners + R.band_owner) * R.band_rows + (rl % R.band_rows);
-            const bool real = j < R.height;
-            const bool split = rl >= wr0 && rl < wr1 && R.win_nx != 0u; // this row crosses the window: skip its columns
-            float* row = out + (size_t)rl * R.width * 3;
-            for (uint32_t f = threadIdx.x; f < R.width * 3u; f += kBlock) {
-                const uint32_t i = f / 3u, c = f - i * 3u;
-                if (split && i >= wi0 && i < wi1) continue;
-                row[f] = real ? (c == 0u ? b0 : (c == 1u ? b1 : b2)) : 0.0f;
-            }
-        }
-    }
+    // The pixels outside the window cannot be reached by the scene (screen_bounds()): every sample returns the background, the
+    // pixel holds their f32 sum in sample order (padding rows of the last band: zero).  Rows are dealt round-robin to the
+    // workgroups; the window's own pixels are written by the tiles below, so no pixel has two writers.  Mesh kernels fill their
+    // rows in a prologue, all threads of the workgroup on one row; with workgroup lists (grab == 0) the rows are the TAIL of
+    // the list — a quarter of a row per entry — so they are written by whichever waves run out of tiles first, not by the wave that
+    // still sits on the frame's longest tile.
+    const bool fill_rows = R.win_nx < tiles_x || R.win_ny < tiles_y;
+    auto fill_row = [&](uint32_t rl, uint32_t t0, uint32_t tstep) { // threads t0, t0 + tstep, ... of the row's W * 3 floats
+        fill_background_row(S.background[0], S.background[1], S.background[2], R.spp, out, R.width, R.height, R.band_rows, R.band_owner, R.band_owners,
+                            R.win_x0, R.win_nx, R.win_y0, R.win_ny, lane_log2, rl, t0, tstep);
+    };
+    if (fill_rows && grab != 0u)
+        for (uint32_t rl = blockIdx.x; rl < R.rows_local; rl += gridDim.x) fill_row(rl, threadIdx.x, kBlock);
 
     // grab == 0 (cheap analytic scenes, ~1 us tiles): the wave tiles are dealt round-robin to the workgroups and
     // the four waves of a workgroup pull from their list through an LDS counter — list scheduling inside the
@@ -215,8 +236,23 @@ __global__ void __launch_bounds__(kBlock, waves_per_simd(FEAT)) k_primary(DScene
       if (grab == 0u) {
           uint32_t k = 0;
           if (lane == 0u) k = atomicAdd(&block_next, 1u); // LDS: ~100 cycles, no prefetch needed
-          first = (uint32_t)__builtin_amdgcn_readfirstlane((int)k) * gridDim.x + blockIdx.x;
-          if (first >= nwt) break;
+          const uint32_t kk = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
+          // this workgroup's list: (lead workgroups only) its share of the `heavy` most expensive entries of the order, then
+          // its share of the other entries, then its share of the rows outside the window (a quarter of a row per entry)
+          const uint32_t G = gridDim.x, b = blockIdx.x, Gh = R.tile_order ? R.lead_wgs : 0u;
+          const uint32_t heavy = Gh ? (nwt < 4u * Gh ? nwt : 4u * Gh) : 0u;
+          const uint32_t nhb = (b < Gh && heavy > b) ? (heavy - b + Gh - 1u) / Gh : 0u;
+          const uint32_t ncb = nwt - heavy > b ? (nwt - heavy - b + G - 1u) / G : 0u;
+          if (kk < nhb) first = b + Gh * kk;
+          else if (kk - nhb < ncb) first = heavy + (kk - nhb) * G + b;
+          else { // the tiles are taken: rows
+              if (!fill_rows) break;
+              const uint32_t part = kk - nhb - ncb;
+              const uint32_t rl = (part >> 2) * G + b;
+              if (rl >= R.rows_local) break;
+              fill_row(rl, (part & 3u) * 64u + lane, kBlock);
+              continue;
+          }
           // with the costs of an earlier frame of this camera: entry e of the descending-cost order instead of wave tile e,
           // so the few hundred expensive tiles of a frame (deep reflection chains) are dealt one to a WAVE and start first
           // instead of piling up in the workgroups whose columns cross them
@@ -247,6 +283,9 @@ __global__ void __launch_bounds__(kBlock, waves_per_simd(FEAT)) k_primary(DScene
       }
       for (uint32_t wt = first; wt < last; ++wt) {
         const unsigned long long tile_t0 = R.tile_cost ? __builtin_readcyclecounter() : 0ULL;
+#ifdef NR_DEBUG_TILE_COSTS
+        if (dbg_tiles++ == 0u) dbg_t_first = (uint32_t)__builtin_amdgcn_s_memrealtime();
+#endif
         uint32_t i, rl; // column, local (compact) row
         uint32_t q = 0u; // which of the pixel's side-by-side samples this lane traces
         if (lane_log2 == 0u) {
@@ -325,6 +364,13 @@ __global__ void __launch_bounds__(kBlock, waves_per_simd(FEAT)) k_primary(DScene
     }
 #ifdef NR_PHASE_TIMING
     cnt.cyc_other = (unsigned)(__builtin_readcyclecounter() - twave);
+#endif
+#ifdef NR_DEBUG_TILE_COSTS
+    if (R.wave_times && lane == 0u) {
+        uint32_t* w = R.wave_times + 4u * (blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6));
+        uint32_t hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        w[0] = dbg_t_entry; w[1] = dbg_t_first; w[2] = (uint32_t)__builtin_amdgcn_s_memrealtime(); w[3] = dbg_tiles | (xcc_id() << 28) | ((hw & 0xffffu) << 12);
+    }
 #endif
     flush_counters(ctr, cnt, STATS);
 }
@@ -543,6 +589,9 @@ struct NraysScene {
     // ... and the sort also reports the sum and the maximum of the costs: their ratio is the frame's parallelism, which
     // decides between cost-ordered lists on ONE workgroup per CU (few long tiles: a wave alone on its SIMD finishes a
     // deep reflection chain sooner) and image-order lists on two (many tiles: throughput)
+#ifdef NR_DEBUG_TILE_COSTS
+    uint32_t* d_wave_times = nullptr; uint32_t dbg_grid = 0;
+#endif
     unsigned long long* d_cost_stats = nullptr; unsigned long long* h_cost_stats = nullptr; hipEvent_t ev_stats = nullptr;
     bool stats_pending = false, lone_waves = false;
     uint32_t spill_entries = 0; // HBM stack entries per lane beyond the kLdsStack entries kept in LDS (0 = never needed)
@@ -575,6 +624,7 @@ struct NraysScene {
     bool lpt_enabled = true;                        // NRAYS_LPT=0 restores image order
     bool lpt_analytic = true;                       // NRAYS_LPT_ANALYTIC=0: analytic scenes never switch to cost-ordered lists on one workgroup per CU
     int grid_wg_per_cu = 0;                         // NRAYS_GRID_WG_PER_CU=n caps the persistent grid at n workgroups per CU (tuning)
+    bool lead_mode = true;                          // NRAYS_LEAD_WGS=0: cost-ordered lists run on one workgroup per CU instead of lead + second workgroups
     bool cull_enabled = true;                       // NRAYS_SCREEN_CULL=0: no wave tile is decided from the scene's screen bounds
     NraysStats last;
     uint64_t last_primary = 0, last_primary_first_batch = 0;
@@ -864,9 +914,18 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
         }
         if (sc->order_valid && sc->order_key == key && sc->lone_waves && !sc->stats_pending) {
             R.tile_order = sc->d_tile_order;
-            grid_primary = std::min<uint32_t>(grid_primary, (uint32_t)sc->num_cus);
+            if (sc->lead_mode) R.lead_wgs = std::min<uint32_t>(grid_primary, (uint32_t)sc->num_cus); // two workgroups per CU: one of them owns the long tiles
+            else grid_primary = std::min<uint32_t>(grid_primary, (uint32_t)sc->num_cus);             // NRAYS_LEAD_WGS=0: one workgroup per CU
         }
+#ifdef NR_DEBUG_TILE_COSTS
+        if (getenv("NRAYS_DEBUG_RECORD_ALWAYS")) R.tile_cost = sc->d_tile_cost; // tools/tile_costs.py: the costs of the steady-state frames
+#endif
     }
+#ifdef NR_DEBUG_TILE_COSTS
+    if (!sc->d_wave_times) HIP_TRY(hipMalloc((void**)&sc->d_wave_times, (size_t)kMaxGrid * (kBlock / 64) * 4 * sizeof(uint32_t)));
+    HIP_TRY(hipMemsetAsync(sc->d_wave_times, 0, (size_t)kMaxGrid * (kBlock / 64) * 4 * sizeof(uint32_t), stream));
+    R.wave_times = sc->d_wave_times; sc->dbg_grid = grid_primary;
+#endif
     bool first_primary = true;
     for (uint32_t s0 = 0; s0 < p->ray_per_pixel; s0 += batch) {
         R.sample_begin = s0; R.sample_end = std::min<uint32_t>(p->ray_per_pixel, s0 + batch);
@@ -1027,6 +1086,7 @@ int nrays_scene_create(const NraysSceneDesc* desc, NraysScene** out_scene) {
     if (const char* e = getenv("NRAYS_LPT")) sc->lpt_enabled = atoi(e) != 0;
     if (const char* e = getenv("NRAYS_SCREEN_CULL")) sc->cull_enabled = atoi(e) != 0;
     if (const char* e = getenv("NRAYS_LPT_ANALYTIC")) sc->lpt_analytic = atoi(e) != 0;
+    if (const char* e = getenv("NRAYS_LEAD_WGS")) sc->lead_mode = atoi(e) != 0;
     if (const char* e = getenv("NRAYS_GRID_WG_PER_CU")) sc->grid_wg_per_cu = std::max(0, atoi(e));
     // release bulk host copies
     std::vector<BvhNode>().swap(h.nodes); std::vector<TriRec>().swap(h.tris); std::vector<TriUv>().swap(h.triuvs);
@@ -1131,6 +1191,15 @@ int nrays_debug_tile_costs(NraysScene* sc, uint32_t* out, uint32_t capacity, uin
     const uint32_t n = std::min(capacity, sc->tile_slots);
     HIP_TRY(hipMemcpy(out, sc->d_tile_cost, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
     *out_count = n;
+    return NRAYS_OK;
+}
+// Tuning builds only (tools/wave_timeline.py): {kernel entry, first tile, exit, tiles} per wave of the last primary launch, 10 ns ticks.
+int nrays_debug_wave_times(NraysScene* sc, uint32_t* out, uint32_t capacity_waves, uint32_t* out_waves) {
+    if (!sc || !sc->have_last || !sc->d_wave_times) return NRAYS_ERR_BAD_ARG;
+    HIP_TRY(hipStreamSynchronize(sc->last_stream));
+    const uint32_t n = std::min<uint32_t>(capacity_waves, sc->dbg_grid * (kBlock / 64));
+    HIP_TRY(hipMemcpy(out, sc->d_wave_times, (size_t)n * 4 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    *out_waves = n;
     return NRAYS_OK;
 }
 #endif

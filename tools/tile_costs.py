@@ -16,7 +16,7 @@ for name in sys.argv[1:] or ["sponza"]:
                "balls": su.balls_scene, "primitives": lambda: su.primitives_scene(0.0, 1)}[name]()
     p, _ = su.camera_params(cam, 1920, 1080)
     out = torch.empty((1080, 1920, 3), dtype=torch.float32, device="cuda")
-    for _ in range(3):
+    for _ in range(8 if os.environ.get("NRAYS_DEBUG_RECORD_ALWAYS") else 3):  # with NRAYS_DEBUG_RECORD_ALWAYS=1: the costs of a steady-state frame
         abi.check(lib.nrays_render_device(sc.device_handle(), C.byref(p), C.c_void_p(out.data_ptr()), None))
     cap = 1 << 20
     buf = np.zeros(cap, np.uint32); n = C.c_uint32()

@@ -1,0 +1,40 @@
+#!/usr/bin/env python
+"""When the waves of the primary kernel start, reach their first tile and exit (GPU box; needs a -DNR_DEBUG_TILE_COSTS build):
+  NRAYS_HIP_LIB=nrays_amd/lib/variants/tc.so python tools/wave_timeline.py balls [frames]
+Prints the span of the launch (first entry -> last exit), percentiles of the waves' entry / first-tile / exit times relative to the
+first entry, and the tiles of the waves that exit last."""
+import ctypes as C, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+from nrays_amd import abi
+from tests import scenes_util as su, standins
+lib = abi.load_hip_lib()
+name = sys.argv[1] if len(sys.argv) > 1 else "balls"
+frames = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+sc, cam = {"sponza": standins.sponza_scene, "hairball": standins.hairball_scene, "balls": su.balls_scene,
+           "ballsfar": lambda: (su.balls_scene()[0], dict(su.balls_scene()[1], eye=(0.0, 150.0, -300.0))),
+           "primitives": lambda: su.primitives_scene(0.0, 1)}[name]()
+p, _ = su.camera_params(cam, 1920, 1080)
+out = torch.empty((1080, 1920, 3), dtype=torch.float32, device="cuda")
+lib.nrays_debug_wave_times.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+for f in range(frames):
+    abi.check(lib.nrays_render_device(sc.device_handle(), C.byref(p), C.c_void_p(out.data_ptr()), None))
+    buf = np.zeros((8192, 4), np.uint32); n = C.c_uint32()
+    abi.check(lib.nrays_debug_wave_times(sc.device_handle(), buf.ctypes.data, 8192, C.byref(n)))
+    w = buf[:n.value].astype(np.int64)
+    w = w[w[:, 2] != 0]
+    hw = w[:, 3] >> 12; w[:, 3] &= 0xfff  # xcc << 16 | HW_ID[15:0] (gfx9: cu_id 11:8, sh_id 12, se_id 15:13)
+    cu = (hw >> 8) & 0xfff  # xcc, se, sh, cu: one value per CU
+    wg = np.arange(len(w)) // 4
+    pairs = {}
+    for c, g in zip(cu, wg): pairs.setdefault(int(c), set()).add(int(g))
+    lead = sum(1 for v in pairs.values() if sum(1 for g in v if g < 256) == 1)
+    t0 = w[:, 0].min()
+    ent, first, ex = (w[:, 0] - t0) / 100.0, np.where(w[:, 3] > 0, (w[:, 1] - t0) / 100.0, np.nan), (w[:, 2] - t0) / 100.0
+    q = lambda a: [round(float(x), 1) for x in np.nanpercentile(a, [0, 50, 90, 99, 100])]
+    last = np.argsort(ex)[-3:][::-1]
+    print(json.dumps({"scene": name, "frame": f, "waves": int(len(w)), "span_us": round(float(ex.max()), 1),
+                      "entry_us_p0_50_90_99_100": q(ent), "first_tile_us": q(first), "exit_us": q(ex),
+                      "cus": len(pairs), "cus_with_exactly_one_of_the_first_256_workgroups": lead, "last_waves": [{"exit_us": round(float(ex[i]), 1), "entry_us": round(float(ent[i]), 1), "tiles": int(w[i, 3])} for i in last]}), flush=True)
