@@ -209,6 +209,7 @@ struct DRender {
     // own the 4 * lead_wgs most expensive entries, one per wave, so every long tile starts at once on a SIMD of its own;
     // the remaining entries (and the rows outside the window) are dealt to ALL workgroups.  0 = one uniform list.
     uint32_t lead_wgs;
+    uint32_t lead_entries; // how many entries the lead workgroups own (lead_wgs * 1..4)
     double window_width;
     double eye[3];
     double m[16];                // (P V)^-1 column-major

@@ -240,7 +240,7 @@ __global__ void __launch_bounds__(kBlock, waves_per_simd(FEAT)) k_primary(DScene
           // this workgroup's list: (lead workgroups only) its share of the `heavy` most expensive entries of the order, then
           // its share of the other entries, then its share of the rows outside the window (a quarter of a row per entry)
           const uint32_t G = gridDim.x, b = blockIdx.x, Gh = R.tile_order ? R.lead_wgs : 0u;
-          const uint32_t heavy = Gh ? (nwt < 4u * Gh ? nwt : 4u * Gh) : 0u;
+          const uint32_t heavy = Gh ? (nwt < R.lead_entries ? nwt : R.lead_entries) : 0u;
           const uint32_t nhb = (b < Gh && heavy > b) ? (heavy - b + Gh - 1u) / Gh : 0u;
           const uint32_t ncb = nwt - heavy > b ? (nwt - heavy - b + G - 1u) / G : 0u;
           if (kk < nhb) first = b + Gh * kk;
@@ -624,6 +624,7 @@ struct NraysScene {
     bool lpt_enabled = true;                        // NRAYS_LPT=0 restores image order
     bool lpt_analytic = true;                       // NRAYS_LPT_ANALYTIC=0: analytic scenes never switch to cost-ordered lists on one workgroup per CU
     int grid_wg_per_cu = 0;                         // NRAYS_GRID_WG_PER_CU=n caps the persistent grid at n workgroups per CU (tuning)
+    int lead_per_wg = 4;                            // NRAYS_LEAD_PER_WG=1..4: long entries per lead workgroup
     bool lead_mode = true;                          // NRAYS_LEAD_WGS=0: cost-ordered lists run on one workgroup per CU instead of lead + second workgroups
     bool cull_enabled = true;                       // NRAYS_SCREEN_CULL=0: no wave tile is decided from the scene's screen bounds
     NraysStats last;
@@ -914,7 +915,7 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
         }
         if (sc->order_valid && sc->order_key == key && sc->lone_waves && !sc->stats_pending) {
             R.tile_order = sc->d_tile_order;
-            if (sc->lead_mode) R.lead_wgs = std::min<uint32_t>(grid_primary, (uint32_t)sc->num_cus); // two workgroups per CU: one of them owns the long tiles
+            if (sc->lead_mode) { R.lead_wgs = std::min<uint32_t>(grid_primary, (uint32_t)sc->num_cus); R.lead_entries = R.lead_wgs * (uint32_t)sc->lead_per_wg; } // two workgroups per CU: one of them owns the long tiles
             else grid_primary = std::min<uint32_t>(grid_primary, (uint32_t)sc->num_cus);             // NRAYS_LEAD_WGS=0: one workgroup per CU
         }
 #ifdef NR_DEBUG_TILE_COSTS
@@ -1087,6 +1088,7 @@ int nrays_scene_create(const NraysSceneDesc* desc, NraysScene** out_scene) {
     if (const char* e = getenv("NRAYS_SCREEN_CULL")) sc->cull_enabled = atoi(e) != 0;
     if (const char* e = getenv("NRAYS_LPT_ANALYTIC")) sc->lpt_analytic = atoi(e) != 0;
     if (const char* e = getenv("NRAYS_LEAD_WGS")) sc->lead_mode = atoi(e) != 0;
+    if (const char* e = getenv("NRAYS_LEAD_PER_WG")) sc->lead_per_wg = std::max(1, std::min(64, atoi(e)));
     if (const char* e = getenv("NRAYS_GRID_WG_PER_CU")) sc->grid_wg_per_cu = std::max(0, atoi(e));
     // release bulk host copies
     std::vector<BvhNode>().swap(h.nodes); std::vector<TriRec>().swap(h.tris); std::vector<TriUv>().swap(h.triuvs);
