@@ -624,6 +624,7 @@ struct NraysScene {
     bool lpt_enabled = true;                        // NRAYS_LPT=0 restores image order
     bool lpt_analytic = true;                       // NRAYS_LPT_ANALYTIC=0: analytic scenes never switch to cost-ordered lists on one workgroup per CU
     int grid_wg_per_cu = 0;                         // NRAYS_GRID_WG_PER_CU=n caps the persistent grid at n workgroups per CU (tuning)
+    double lone_factor = 1.5;                       // NRAYS_LONE_FACTOR: cost-ordered lead / second lists when sum / max of the tile costs < factor * SIMDs
     int lead_per_wg = 4;                            // NRAYS_LEAD_PER_WG=1..4: long entries per lead workgroup
     bool lead_mode = true;                          // NRAYS_LEAD_WGS=0: cost-ordered lists run on one workgroup per CU instead of lead + second workgroups
     bool cull_enabled = true;                       // NRAYS_SCREEN_CULL=0: no wave tile is decided from the scene's screen bounds
@@ -888,7 +889,7 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
         mix(&p->ray_per_pixel, sizeof p->ray_per_pixel); mix(&p->max_depth, sizeof p->max_depth);
         if (sc->stats_pending && hipEventQuery(sc->ev_stats) == hipSuccess) { // the sum / maximum of the last sort have arrived
             const double sum = (double)sc->h_cost_stats[0], mx = (double)sc->h_cost_stats[1];
-            sc->lone_waves = mx > 0.0 && sum / mx < 1.5 * 4.0 * (double)sc->num_cus;
+            sc->lone_waves = mx > 0.0 && sum / mx < sc->lone_factor * 4.0 * (double)sc->num_cus;
             sc->stats_pending = false;
         }
         auto sort_costs = [&]() -> int {
@@ -1088,6 +1089,7 @@ int nrays_scene_create(const NraysSceneDesc* desc, NraysScene** out_scene) {
     if (const char* e = getenv("NRAYS_SCREEN_CULL")) sc->cull_enabled = atoi(e) != 0;
     if (const char* e = getenv("NRAYS_LPT_ANALYTIC")) sc->lpt_analytic = atoi(e) != 0;
     if (const char* e = getenv("NRAYS_LEAD_WGS")) sc->lead_mode = atoi(e) != 0;
+    if (const char* e = getenv("NRAYS_LONE_FACTOR")) sc->lone_factor = atof(e);
     if (const char* e = getenv("NRAYS_LEAD_PER_WG")) sc->lead_per_wg = std::max(1, std::min(64, atoi(e)));
     if (const char* e = getenv("NRAYS_GRID_WG_PER_CU")) sc->grid_wg_per_cu = std::max(0, atoi(e));
     // release bulk host copies
