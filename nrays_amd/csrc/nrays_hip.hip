@@ -835,7 +835,10 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
     // mesh scenes: longest-processing-time-first from the previous frame of the same geometry (pixels do not depend on it)
     R.tile_cost = nullptr; R.tile_order = nullptr;
     sc->has_prepass[slot] = false;
-    bool lpt = grab >= 1u;
+    // (not for the sample-major frames of anti-aliased renders: their wave tiles are a few pixels each — 8 M of them for config 5 —
+    // and far more even; recording, sorting and following the order costs more than the tail it removes: hairball 4K 64 spp
+    // 251 -> 222 ms without it, sponza 1080p 4 / 16 / 64 spp 2-4 %, profiles/r02_aa_lpt.log)
+    bool lpt = grab >= 1u && lane_log2 == 0u;
     lpt = lpt && sc->lpt_enabled; // A/B switch (NRAYS_LPT=0)
     if (lpt) {
         const uint32_t nwt = std::max<uint32_t>(1u, lane_log2 ? win_units : win_units * 4u);
