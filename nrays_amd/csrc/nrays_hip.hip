@@ -622,6 +622,7 @@ struct NraysScene {
     bool last_timed = true;
     int grab_override = -1;                         // NRAYS_GRAB
     bool lpt_enabled = true;                        // NRAYS_LPT=0 restores image order
+    bool lpt_reuse = true;                          // NRAYS_LPT_REUSE=0: mesh scenes re-sort their tiles every frame even when the camera rests
     bool lpt_analytic = true;                       // NRAYS_LPT_ANALYTIC=0: analytic scenes never switch to cost-ordered lists on one workgroup per CU
     int grid_wg_per_cu = 0;                         // NRAYS_GRID_WG_PER_CU=n caps the persistent grid at n workgroups per CU (tuning)
     double lone_factor = 1.5;                       // NRAYS_LONE_FACTOR: cost-ordered lead / second lists when sum / max of the tile costs < factor * SIMDs
@@ -845,23 +846,35 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
         if (nwt > sc->tile_slots) {
             if (sc->d_tile_cost) { (void)hipFree(sc->d_tile_cost); sc->d_tile_cost = nullptr; }
             if (sc->d_tile_order) { (void)hipFree(sc->d_tile_order); sc->d_tile_order = nullptr; }
-            sc->tile_slots = 0; sc->cost_valid = false;
+            sc->tile_slots = 0; sc->cost_valid = false; sc->order_valid = false;
             HIP_TRY(hipMalloc((void**)&sc->d_tile_cost, (size_t)nwt * sizeof(uint32_t)));
             HIP_TRY(hipMalloc((void**)&sc->d_tile_order, (size_t)nwt * sizeof(uint32_t)));
             sc->tile_slots = nwt;
         }
         const uint64_t key = (((uint64_t)p->width << 40) ^ ((uint64_t)rows << 20) ^ ((uint64_t)p->band_rows << 8) ^ ((uint64_t)p->band_owner << 4) ^ (uint64_t)R.band_owners ^ ((uint64_t)lane_log2 << 60))
                              + 0x9E3779B97F4A7C15ull * (((uint64_t)R.win_x0 << 48) ^ ((uint64_t)R.win_nx << 32) ^ ((uint64_t)R.win_y0 << 16) ^ (uint64_t)R.win_ny);
-        if (sc->cost_valid && sc->cost_key == key) {
-            if (timed) HIP_TRY(hipEventRecord(sc->ev_begin[slot], stream));
-            sc->has_prepass[slot] = true;
-            hipLaunchKernelGGL(k_tile_order, dim3(8), dim3(1024), 0, stream, sc->d_tile_cost, sc->d_tile_order, nwt, (unsigned long long*)nullptr);
-            HIP_TRY(hipGetLastError());
+        // everything a tile's cost depends on besides the scene (which a handle never changes): a resting camera reuses its order
+        // and records nothing — k_tile_order and the two s_memtime + one store per tile are only paid while the camera moves
+        uint64_t cam = 0xcbf29ce484222325ull; // FNV-1a
+        auto mix = [&](const void* q, size_t n) { const unsigned char* b = (const unsigned char*)q; for (size_t i = 0; i < n; ++i) { cam ^= b[i]; cam *= 0x100000001b3ull; } };
+        mix(p->inv_proj_view, sizeof p->inv_proj_view); mix(p->camera_eye, sizeof p->camera_eye); mix(&p->window_width, sizeof p->window_width);
+        mix(&p->ray_per_pixel, sizeof p->ray_per_pixel); mix(&p->max_depth, sizeof p->max_depth);
+        if (sc->order_valid && sc->order_key == key && sc->order_cam == cam && sc->lpt_reuse) {
             R.tile_order = sc->d_tile_order;
             grab = 1u;
+        } else {
+            if (sc->cost_valid && sc->cost_key == key) {
+                if (timed) HIP_TRY(hipEventRecord(sc->ev_begin[slot], stream));
+                sc->has_prepass[slot] = true;
+                hipLaunchKernelGGL(k_tile_order, dim3(8), dim3(1024), 0, stream, sc->d_tile_cost, sc->d_tile_order, nwt, (unsigned long long*)nullptr);
+                HIP_TRY(hipGetLastError());
+                R.tile_order = sc->d_tile_order;
+                grab = 1u;
+                sc->order_valid = true; sc->order_key = key; sc->order_cam = sc->cost_cam;
+            }
+            R.tile_cost = sc->d_tile_cost;
+            sc->cost_key = key; sc->cost_cam = cam; sc->cost_valid = true;
         }
-        R.tile_cost = sc->d_tile_cost;
-        sc->cost_key = key; sc->cost_valid = true;
     }
     // Analytic scenes (workgroup lists): the frames are a few hundred long tiles (deep reflection chains, ~10^5 cycles each) among
     // thousands of short ones, and a long tile runs ~1.5x faster when its wave has the SIMD to itself.  The first frame of a
@@ -1091,6 +1104,7 @@ int nrays_scene_create(const NraysSceneDesc* desc, NraysScene** out_scene) {
     if (const char* e = getenv("NRAYS_LPT")) sc->lpt_enabled = atoi(e) != 0;
     if (const char* e = getenv("NRAYS_SCREEN_CULL")) sc->cull_enabled = atoi(e) != 0;
     if (const char* e = getenv("NRAYS_LPT_ANALYTIC")) sc->lpt_analytic = atoi(e) != 0;
+    if (const char* e = getenv("NRAYS_LPT_REUSE")) sc->lpt_reuse = atoi(e) != 0;
     if (const char* e = getenv("NRAYS_LEAD_WGS")) sc->lead_mode = atoi(e) != 0;
     if (const char* e = getenv("NRAYS_LONE_FACTOR")) sc->lone_factor = atof(e);
     if (const char* e = getenv("NRAYS_LEAD_PER_WG")) sc->lead_per_wg = std::max(1, std::min(64, atoi(e)));
