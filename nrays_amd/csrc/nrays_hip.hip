@@ -962,13 +962,18 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
             first_primary = false;
         }
         // rounds of queued second children (host-controlled: the count is read back after every round)
+        // k_bounce takes its ray count from device memory and strides over it, so a round can be launched without knowing the
+        // count: the host only looks (one small copy + a stream synchronisation) before every FOURTH round — to stop, and to size
+        // that group's grids — instead of before every round; a group's later rounds may find an empty queue and return at once.
+        uint32_t n_seen = 0;
         for (uint32_t r = 1; queued && r <= (uint32_t)kMaxGenerations; ++r) {
-            uint32_t n = 0;
-            HIP_TRY(hipMemcpyAsync(&n, sc->d_counts + r, sizeof n, hipMemcpyDeviceToHost, stream));
-            HIP_TRY(hipStreamSynchronize(stream));
-            if (n == 0) break;
-            uint32_t launch_n = std::min<uint32_t>(n, sc->queue_capacity);
-            uint32_t grid = std::min<uint32_t>((launch_n + kBlock - 1) / kBlock, kMaxGrid);
+            if ((r - 1u) % 4u == 0u) {
+                HIP_TRY(hipMemcpyAsync(&n_seen, sc->d_counts + r, sizeof n_seen, hipMemcpyDeviceToHost, stream));
+                HIP_TRY(hipStreamSynchronize(stream));
+                if (n_seen == 0) break;
+            }
+            uint32_t launch_n = std::min<uint32_t>(n_seen, sc->queue_capacity); // the group's first count bounds nothing, it only sizes the grid
+            uint32_t grid = std::max<uint32_t>(std::min<uint32_t>((launch_n + kBlock - 1) / kBlock, kMaxGrid), std::min<uint32_t>((uint32_t)sc->num_cus, kMaxGrid));
             QueueOut qn; qn.q = sc->queue[(r + 1) & 1].q; qn.capacity = sc->queue_capacity; qn.count = sc->d_counts + r + 1;
             qn.overflow = &sc->d_counters->overflow;
             if (instrumented) hipLaunchKernelGGL(k_bounce<true>, dim3(grid), dim3(kBlock), 0, stream, sc->d, sc->queue[r & 1].q, sc->d_counts + r, sc->queue_capacity, qn, d_out, sc->d_counters, sc->d_spill, p->max_depth);
