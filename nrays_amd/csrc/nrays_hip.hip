@@ -587,11 +587,8 @@ struct NraysScene {
     // the order is then reused as long as the camera stays (the scene of a handle never changes)
     uint64_t cost_cam = 0, order_key = 0, order_cam = 0; bool order_valid = false; uint32_t order_age = 0;
     // ... and the sort also reports the sum and the maximum of the costs: their ratio is the frame's parallelism, which
-    // decides between cost-ordered lists on ONE workgroup per CU (few long tiles: a wave alone on its SIMD finishes a
-    // deep reflection chain sooner) and image-order lists on two (many tiles: throughput)
-#ifdef NR_DEBUG_TILE_COSTS
-    uint32_t* d_wave_times = nullptr; uint32_t dbg_grid = 0;
-#endif
+    // decides between cost-ordered lists with the long tiles on the first workgroup of each CU (few long tiles) and image-order
+    // lists (many tiles: throughput)
     unsigned long long* d_cost_stats = nullptr; unsigned long long* h_cost_stats = nullptr; hipEvent_t ev_stats = nullptr;
     bool stats_pending = false, lone_waves = false;
     uint32_t spill_entries = 0; // HBM stack entries per lane beyond the kLdsStack entries kept in LDS (0 = never needed)
@@ -623,7 +620,7 @@ struct NraysScene {
     int grab_override = -1;                         // NRAYS_GRAB
     bool lpt_enabled = true;                        // NRAYS_LPT=0 restores image order
     bool lpt_reuse = true;                          // NRAYS_LPT_REUSE=0: mesh scenes re-sort their tiles every frame even when the camera rests
-    bool lpt_analytic = true;                       // NRAYS_LPT_ANALYTIC=0: analytic scenes never switch to cost-ordered lists on one workgroup per CU
+    bool lpt_analytic = true;                       // NRAYS_LPT_ANALYTIC=0: analytic scenes never switch to cost-ordered lists
     int grid_wg_per_cu = 0;                         // NRAYS_GRID_WG_PER_CU=n caps the persistent grid at n workgroups per CU (tuning)
     double lone_factor = 1.5;                       // NRAYS_LONE_FACTOR: cost-ordered lead / second lists when sum / max of the tile costs < factor * SIMDs
     int lead_per_wg = 4;                            // NRAYS_LEAD_PER_WG=1..4: long entries per lead workgroup
@@ -877,11 +874,11 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
         }
     }
     // Analytic scenes (workgroup lists): the frames are a few hundred long tiles (deep reflection chains, ~10^5 cycles each) among
-    // thousands of short ones, and a long tile runs ~1.5x faster when its wave has the SIMD to itself.  The first frame of a
-    // camera records the tile costs, the second sorts them (k_tile_order) and reads back their sum and maximum; when the frame's
-    // parallelism sum / max is below ~1.5 waves per SIMD of the chip, the following frames of that camera deal the tiles in
-    // descending cost order to ONE workgroup per CU — otherwise image order on two, as before (profiles/r02_analytic_lpt.log:
-    // balls 71.1 -> 61.2 us; primitives, whose every tile is long, 202 us with two workgroups against 293 with one).
+    // thousands of short ones, and a long tile runs ~1.5x faster when it does not share its SIMD with another long one.  The first
+    // frame of a camera records the tile costs, the second sorts them (k_tile_order) and reads back their sum and maximum; when the
+    // frame's parallelism sum / max is below ~1.5 waves per SIMD of the chip, the following frames of that camera are rendered from
+    // the cost order with the long tiles on the first workgroup of each CU (DRender::lead_wgs, k_primary) — otherwise image order,
+    // as before (profiles/r02_analytic_lpt.log: balls 70.0 -> 52.4 us; primitives, whose every tile is long, stays at 201 us).
     if (grab == 0u && sc->lpt_analytic && !instrumented && win_units > 0) {
         const uint32_t nwt = lane_log2 ? win_units : win_units * 4u;
         if (nwt > sc->tile_slots) {
