@@ -589,6 +589,9 @@ struct NraysScene {
     // ... and the sort also reports the sum and the maximum of the costs: their ratio is the frame's parallelism, which
     // decides between cost-ordered lists with the long tiles on the first workgroup of each CU (few long tiles) and image-order
     // lists (many tiles: throughput)
+#ifdef NR_DEBUG_TILE_COSTS
+    uint32_t* d_wave_times = nullptr; uint32_t dbg_grid = 0;
+#endif
     unsigned long long* d_cost_stats = nullptr; unsigned long long* h_cost_stats = nullptr; hipEvent_t ev_stats = nullptr;
     bool stats_pending = false, lone_waves = false;
     uint32_t spill_entries = 0; // HBM stack entries per lane beyond the kLdsStack entries kept in LDS (0 = never needed)
