@@ -903,7 +903,9 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
         auto mix = [&](const void* q, size_t n) { const unsigned char* b = (const unsigned char*)q; for (size_t i = 0; i < n; ++i) { cam ^= b[i]; cam *= 0x100000001b3ull; } };
         mix(p->inv_proj_view, sizeof p->inv_proj_view); mix(p->camera_eye, sizeof p->camera_eye); mix(&p->window_width, sizeof p->window_width);
         mix(&p->ray_per_pixel, sizeof p->ray_per_pixel); mix(&p->max_depth, sizeof p->max_depth);
-        if (sc->stats_pending && hipEventQuery(sc->ev_stats) == hipSuccess) { // the sum / maximum of the last sort have arrived
+        const hipError_t stats_ready = sc->stats_pending ? hipEventQuery(sc->ev_stats) : hipErrorNotReady;
+        if (sc->stats_pending && stats_ready != hipSuccess) (void)hipGetLastError(); // "not ready" must not surface as the launch error checked below
+        if (sc->stats_pending && stats_ready == hipSuccess) { // the sum / maximum of the last sort have arrived
             const double sum = (double)sc->h_cost_stats[0], mx = (double)sc->h_cost_stats[1];
             sc->lone_waves = mx > 0.0 && sum / mx < sc->lone_factor * 4.0 * (double)sc->num_cus;
             sc->stats_pending = false;

@@ -163,3 +163,19 @@ def test_repeated_frames_of_a_resting_camera_are_identical(gpu, make):
             assert np.array_equal(got, want)
     ref, ost = oracle.render(a.descriptor, p, 8)
     assert np.abs(first - ref).max() <= 1e-4
+
+
+def test_frames_enqueued_without_synchronisation(gpu):
+    """nrays_render_device only enqueues: fifty frames of one camera issued back to back, so that the asynchronous read-back
+    behind the scheduling decision is still in flight ("not ready") while the following frames are launched.  No call may fail
+    and the last frame equals a synchronous first one."""
+    import torch
+    lib = abi.load_hip_lib()
+    a, cam = su.balls_scene()
+    p, _ = su.camera_params(cam, 960, 540)
+    want, _ = _render(su.balls_scene()[0], p)
+    out = torch.empty((540, 960, 3), dtype=torch.float32, device="cuda")
+    for _ in range(50):
+        abi.check(lib.nrays_render_device(a.device_handle(), C.byref(p), C.c_void_p(out.data_ptr()), None))
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), want)
