@@ -204,6 +204,11 @@ int nrays_scene_create(const NraysSceneDesc* desc, NraysScene** out_scene);
  * untiled render and nrays_tile_rows(params) for a tiled one.  Blocking. */
 int nrays_render(NraysScene* scene, const NraysRenderParams* params, float* out_rgb);
 
+/* The same frame as 8-bit RGB, quantised on the device exactly as Image::to_png does on the host (src/image.rs:66-76:
+ * c * 255, clamped to [0, 255], truncated; NaN -> 0): what the loader3d front-end writes into its PNG, at a quarter of
+ * the device-to-host bytes of nrays_render.  `out_rgb8` is HOST memory, rows*width*3 bytes, same indexing.  Blocking. */
+int nrays_render_rgb8(NraysScene* scene, const NraysRenderParams* params, uint8_t* out_rgb8);
+
 /* Same, but `out_rgb_device` is DEVICE memory on the scene's device and the work is enqueued on
  * `hip_stream` (a hipStream_t, NULL = default stream) without a final synchronisation unless the
  * scene needs host-side generation control (transparent scenes). */

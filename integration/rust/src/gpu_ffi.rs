@@ -158,6 +158,7 @@ extern "C" {
     pub fn nrays_scene_destroy(scene: *mut NraysScene);
     pub fn nrays_scene_device_bytes(scene: *const NraysScene) -> u64;
     pub fn nrays_render(scene: *mut NraysScene, params: *const NraysRenderParams, out_rgb: *mut f32) -> c_int;
+    pub fn nrays_render_rgb8(scene: *mut NraysScene, params: *const NraysRenderParams, out_rgb8: *mut u8) -> c_int;
     pub fn nrays_render_device(scene: *mut NraysScene, params: *const NraysRenderParams, out_rgb_device: *mut f32, hip_stream: *mut c_void) -> c_int;
     pub fn nrays_render_device_instrumented(scene: *mut NraysScene, params: *const NraysRenderParams, out_rgb_device: *mut f32, hip_stream: *mut c_void) -> c_int;
     pub fn nrays_tile_rows(params: *const NraysRenderParams) -> u32;

@@ -94,6 +94,7 @@ class NraysStats(C.Structure):
 HIP_SYMBOLS = {
     "nrays_scene_create": (C.c_int, [C.POINTER(NraysSceneDesc), C.POINTER(C.c_void_p)]),
     "nrays_render": (C.c_int, [C.c_void_p, C.POINTER(NraysRenderParams), C.POINTER(C.c_float)]),
+    "nrays_render_rgb8": (C.c_int, [C.c_void_p, C.POINTER(NraysRenderParams), C.POINTER(C.c_uint8)]),
     "nrays_render_device": (C.c_int, [C.c_void_p, C.POINTER(NraysRenderParams), C.c_void_p, C.c_void_p]),
     "nrays_render_device_instrumented": (C.c_int, [C.c_void_p, C.POINTER(NraysRenderParams), C.c_void_p, C.c_void_p]),
     "nrays_tile_rows": (C.c_uint32, [C.POINTER(NraysRenderParams)]),

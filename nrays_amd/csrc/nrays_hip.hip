@@ -505,6 +505,17 @@ static ScreenBounds screen_bounds(const HostScene& h, const NraysRenderParams* p
     return r;
 }
 
+// Image::to_png quantisation (src/image.rs:66-76) of a finished frame: c * 255, clamped to [0, 255], truncated; NaN and
+// negatives -> 0 (Rust's saturating `as u8`).  Same f32 operations as the host front-end's quantize_rgb8 (png_codec.cpp).
+__global__ void k_quantize_rgb8(const float* __restrict__ rgb, uint8_t* __restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float v = rgb[i] * 255.0f;
+    v = (v > 0.0f) ? v : 0.0f;
+    v = v > 255.0f ? 255.0f : v;
+    out[i] = (uint8_t)(uint32_t)v;
+}
+
 // Per-column / per-row raygen products for jitter-free cameras (see DRender::col_tab): thread t < width
 // writes M[:,0] * dx_t, thread width + t writes M[:,1] * dy_t, with exactly the operations of
 // generate_primary (scene.rs:81-83), so the tabulated path is bit-identical to the direct one.
@@ -598,6 +609,7 @@ struct NraysScene {
     int num_cus = 256;
     int features = kFeatAll;
     float* d_frame = nullptr; size_t frame_floats = 0;
+    uint8_t* d_rgb8 = nullptr; size_t rgb8_bytes = 0; // nrays_render_rgb8
     hipStream_t own_stream = nullptr;
     // ring of HIP event triples (frame begin, primary kernel begin/end, frame end) recorded on the render
     // stream; nrays_get_stats averages the frames recorded since its previous call.
@@ -1155,6 +1167,7 @@ void nrays_scene_destroy(NraysScene* sc) {
     if (sc->d_tile_cost) (void)hipFree(sc->d_tile_cost);
     if (sc->d_tile_order) (void)hipFree(sc->d_tile_order);
     if (sc->d_cost_stats) (void)hipFree(sc->d_cost_stats);
+    if (sc->d_rgb8) (void)hipFree(sc->d_rgb8);
     if (sc->h_cost_stats) (void)hipHostFree(sc->h_cost_stats);
     if (sc->ev_stats) (void)hipEventDestroy(sc->ev_stats);
     if (sc->d_counters_primary) (void)hipFree(sc->d_counters_primary);
@@ -1271,6 +1284,34 @@ int nrays_render(NraysScene* sc, const NraysRenderParams* p, float* out_rgb) {
     int rc = render_impl(sc, p, sc->d_frame, sc->own_stream, false);
     if (rc != NRAYS_OK) return rc;
     HIP_TRY(hipMemcpyAsync(out_rgb, sc->d_frame, floats * sizeof(float), hipMemcpyDeviceToHost, sc->own_stream));
+    HIP_TRY(hipStreamSynchronize(sc->own_stream));
+    unsigned int overflow = 0;
+    HIP_TRY(hipMemcpy(&overflow, &sc->d_counters->overflow, sizeof overflow, hipMemcpyDeviceToHost));
+    if (overflow) return fail(NRAYS_ERR_QUEUE_OVERFLOW, "continuation-ray queue overflow: image is incomplete");
+    return NRAYS_OK;
+}
+
+int nrays_render_rgb8(NraysScene* sc, const NraysRenderParams* p, uint8_t* out_rgb8) {
+    if (!sc || !p || !out_rgb8) return fail(NRAYS_ERR_BAD_ARG, "null argument");
+    HIP_TRY(hipSetDevice(sc->device));
+    const size_t n = (size_t)tile_rows(p) * p->width * 3;
+    if (n > sc->frame_floats) {
+        if (sc->d_frame) { (void)hipFree(sc->d_frame); sc->d_frame = nullptr; sc->frame_floats = 0; }
+        HIP_TRY(hipMalloc((void**)&sc->d_frame, n * sizeof(float)));
+        sc->frame_floats = n;
+    }
+    if (n > sc->rgb8_bytes) {
+        if (sc->d_rgb8) { (void)hipFree(sc->d_rgb8); sc->d_rgb8 = nullptr; sc->rgb8_bytes = 0; }
+        HIP_TRY(hipMalloc((void**)&sc->d_rgb8, n));
+        sc->rgb8_bytes = n;
+    }
+    int rc = render_impl(sc, p, sc->d_frame, sc->own_stream, false);
+    if (rc != NRAYS_OK) return rc;
+    if (n) {
+        hipLaunchKernelGGL(k_quantize_rgb8, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, sc->own_stream, sc->d_frame, sc->d_rgb8, n);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(out_rgb8, sc->d_rgb8, n, hipMemcpyDeviceToHost, sc->own_stream));
+    }
     HIP_TRY(hipStreamSynchronize(sc->own_stream));
     unsigned int overflow = 0;
     HIP_TRY(hipMemcpy(&overflow, &sc->d_counters->overflow, sizeof overflow, hipMemcpyDeviceToHost));

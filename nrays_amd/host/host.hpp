@@ -26,6 +26,7 @@ Image8 read_png(const std::string& path);
 void write_png_rgb8(const std::string& path, const uint8_t* rgb, uint32_t w, uint32_t h);
 std::vector<uint8_t> quantize_rgb8(const float* rgb, size_t n);
 void write_ppm(const std::string& path, const float* rgb, uint32_t w, uint32_t h);
+void write_ppm_rgb8(const std::string& path, const uint8_t* rgb8, uint32_t w, uint32_t h); // the same file from already quantised bytes
 
 // ImageData (src/texture2d.rs:10-25) after the decode of :99-177: RGBA texels, row 0 = bottom.
 struct ImageData {

@@ -43,6 +43,7 @@ int main(int argc, char** argv) {
         if (!h) { std::fprintf(stderr, "cannot load libnrays_hip.so: %s\n", dlerror()); return 1; }
         auto create = (int (*)(const NraysSceneDesc*, NraysScene**))dlsym(h, "nrays_scene_create");
         auto render = (int (*)(NraysScene*, const NraysRenderParams*, float*))dlsym(h, "nrays_render");
+        auto render_rgb8 = (int (*)(NraysScene*, const NraysRenderParams*, uint8_t*))dlsym(h, "nrays_render_rgb8");
         auto destroy = (void (*)(NraysScene*))dlsym(h, "nrays_scene_destroy");
         auto last_error = (const char* (*)())dlsym(h, "nrays_last_error");
         auto get_stats = (int (*)(NraysScene*, NraysStats*))dlsym(h, "nrays_get_stats");
@@ -52,7 +53,7 @@ int main(int argc, char** argv) {
         auto set_destroy = (void (*)(NraysSceneSet*))dlsym(h, "nrays_scene_set_destroy");
         auto render_multi = (int (*)(NraysSceneSet*, const NraysRenderParams*, float*))dlsym(h, "nrays_render_multi");
         auto multi_stats = (int (*)(NraysSceneSet*, NraysStats*))dlsym(h, "nrays_multi_get_stats");
-        if (!create || !render || !destroy || !last_error || !get_stats || !comm_create_local || !comm_destroy || !set_create || !set_destroy || !render_multi || !multi_stats) {
+        if (!create || !render || !render_rgb8 || !destroy || !last_error || !get_stats || !comm_create_local || !comm_destroy || !set_create || !set_destroy || !render_multi || !multi_stats) {
             std::fprintf(stderr, "libnrays_hip.so lacks an ABI symbol\n"); return 1;
         }
         NraysScene* scene = nullptr; NraysComm* comm = nullptr; NraysSceneSet* set = nullptr;
@@ -69,17 +70,21 @@ int main(int argc, char** argv) {
             inverse_projection(c, (double)p.width, (double)p.height, p.inv_proj_view);
             std::printf("Casting %u rays per pixels (win. %g).\n", p.ray_per_pixel, p.window_width);
             std::printf("Tracing %llu rays.\n", (unsigned long long)p.width * p.height * p.ray_per_pixel);
-            std::vector<float> px((size_t)p.width * p.height * 3);
+            // one GPU: the frame comes back already quantised (Image::to_png's rule, applied on the device: a quarter of the
+            // bytes over PCIe); N GPUs: the float frame of nrays_render_multi, quantised here
+            std::vector<float> px; std::vector<uint8_t> q8;
+            if (set) px.resize((size_t)p.width * p.height * 3); else q8.resize((size_t)p.width * p.height * 3);
             auto t0 = std::chrono::steady_clock::now();
-            if ((set ? render_multi(set, &p, px.data()) : render(scene, &p, px.data())) != NRAYS_OK) { std::fprintf(stderr, "nrays_render: %s\n", last_error()); return 1; }
+            if ((set ? render_multi(set, &p, px.data()) : render_rgb8(scene, &p, q8.data())) != NRAYS_OK) { std::fprintf(stderr, "nrays_render: %s\n", last_error()); return 1; }
             double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             NraysStats st;
             if (set) multi_stats(set, &st); else get_stats(scene, &st);
             unsigned long long rays = st.rays_primary + st.rays_reflection + st.rays_refraction + st.rays_shadow;
             std::printf("Rays cast. %llu rays in %.3f ms (%.1f Mrays/s incl. the device-to-host copy; GPU %.3f ms)\n", rays, ms, rays / ms / 1e3, st.kernel_ms_total);
             std::printf("Saving image to: %s\n", c.output.c_str());
-            if (ppm) write_ppm(c.output, px.data(), p.width, p.height);
-            else { auto q = quantize_rgb8(px.data(), px.size()); write_png_rgb8(c.output, q.data(), p.width, p.height); }
+            if (set) q8 = quantize_rgb8(px.data(), px.size());
+            if (ppm) write_ppm_rgb8(c.output, q8.data(), p.width, p.height);
+            else write_png_rgb8(c.output, q8.data(), p.width, p.height);
             std::printf("Image saved.\n");
         }
         if (set) { set_destroy(set); comm_destroy(comm); } else destroy(scene);

@@ -229,6 +229,9 @@ std::vector<uint8_t> quantize_rgb8(const float* rgb, size_t n) {
 
 void write_ppm(const std::string& path, const float* rgb, uint32_t w, uint32_t h) { // src/image.rs:27-58 (with the clamp fixed)
     std::vector<uint8_t> q = quantize_rgb8(rgb, (size_t)w * h * 3);
+    write_ppm_rgb8(path, q.data(), w, h);
+}
+void write_ppm_rgb8(const std::string& path, const uint8_t* q, uint32_t w, uint32_t h) {
     FILE* f = std::fopen(path.c_str(), "w");
     if (!f) throw std::runtime_error("cannot write " + path);
     std::fprintf(f, "P3\n%u %u\n255\n", w, h);

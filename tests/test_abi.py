@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def declared_functions():
     text = open(os.path.join(ROOT, "include", "nrays_abi.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(nrays_[a-z_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(nrays_[a-z0-9_]+)\s*\(", text)))
 
 
 def test_every_declared_symbol_is_exported(built):

@@ -115,3 +115,27 @@ def test_loader3d_cli_end_to_end(globe, tmp_path):
     (tmp_path / "cli.png").write_bytes(pngs[0])
     got = scenefile.read_png(str(tmp_path / "cli.png"))
     assert np.array_equal(got, _quantise(ref))
+
+
+def test_render_rgb8_is_the_host_quantisation_of_the_float_frame(gpu):
+    """nrays_render_rgb8 quantises on the device with Image::to_png's rule (src/image.rs:66-76: c * 255, clamped, truncated, NaN -> 0):
+    byte for byte what the host front-end's quantize_rgb8 makes of nrays_render's float frame — also for a tiled render."""
+    import ctypes as C
+    import numpy as np
+    import nrays_amd as nr
+    from nrays_amd import abi, tiling
+    from tests import scenes_util as su
+    lib = abi.load_hip_lib()
+    for make in (su.balls_scene, lambda: su.mesh_scene()):
+        sc, cam = make()
+        for kw in (dict(), dict(spp=3, window=1.0, seed=5), dict(band_rows=16, band_owner=1, band_owners=2)):
+            p, _ = su.camera_params(cam, 333, 190, **kw)
+            rows = tiling.tile_rows(p.height, p.band_rows, p.band_owners) if p.band_owners > 1 else p.height
+            f = np.empty((rows, p.width, 3), np.float32)
+            q = np.empty((rows, p.width, 3), np.uint8)
+            abi.check(lib.nrays_render(sc.device_handle(), C.byref(p), f.ctypes.data_as(C.POINTER(C.c_float))))
+            abi.check(lib.nrays_render_rgb8(sc.device_handle(), C.byref(p), q.ctypes.data_as(C.POINTER(C.c_uint8))))
+            v = f * np.float32(255.0)
+            v = np.where(v > 0, v, np.float32(0.0))
+            v = np.minimum(v, np.float32(255.0))
+            assert np.array_equal(q, v.astype(np.uint8)), kw
