@@ -1285,9 +1285,11 @@ int nrays_render(NraysScene* sc, const NraysRenderParams* p, float* out_rgb) {
     if (rc != NRAYS_OK) return rc;
     HIP_TRY(hipMemcpyAsync(out_rgb, sc->d_frame, floats * sizeof(float), hipMemcpyDeviceToHost, sc->own_stream));
     HIP_TRY(hipStreamSynchronize(sc->own_stream));
-    unsigned int overflow = 0;
-    HIP_TRY(hipMemcpy(&overflow, &sc->d_counters->overflow, sizeof overflow, hipMemcpyDeviceToHost));
-    if (overflow) return fail(NRAYS_ERR_QUEUE_OVERFLOW, "continuation-ray queue overflow: image is incomplete");
+    if (sc->host.any_double_branch) { // only scenes with a continuation queue can overflow it: the others skip the extra blocking copy
+        unsigned int overflow = 0;
+        HIP_TRY(hipMemcpy(&overflow, &sc->d_counters->overflow, sizeof overflow, hipMemcpyDeviceToHost));
+        if (overflow) return fail(NRAYS_ERR_QUEUE_OVERFLOW, "continuation-ray queue overflow: image is incomplete");
+    }
     return NRAYS_OK;
 }
 
@@ -1313,9 +1315,11 @@ int nrays_render_rgb8(NraysScene* sc, const NraysRenderParams* p, uint8_t* out_r
         HIP_TRY(hipMemcpyAsync(out_rgb8, sc->d_rgb8, n, hipMemcpyDeviceToHost, sc->own_stream));
     }
     HIP_TRY(hipStreamSynchronize(sc->own_stream));
-    unsigned int overflow = 0;
-    HIP_TRY(hipMemcpy(&overflow, &sc->d_counters->overflow, sizeof overflow, hipMemcpyDeviceToHost));
-    if (overflow) return fail(NRAYS_ERR_QUEUE_OVERFLOW, "continuation-ray queue overflow: image is incomplete");
+    if (sc->host.any_double_branch) { // only scenes with a continuation queue can overflow it: the others skip the extra blocking copy
+        unsigned int overflow = 0;
+        HIP_TRY(hipMemcpy(&overflow, &sc->d_counters->overflow, sizeof overflow, hipMemcpyDeviceToHost));
+        if (overflow) return fail(NRAYS_ERR_QUEUE_OVERFLOW, "continuation-ray queue overflow: image is incomplete");
+    }
     return NRAYS_OK;
 }
 
