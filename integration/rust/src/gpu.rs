@@ -371,6 +371,17 @@ pub fn render(scene: &GpuScene, resolution: &Vless, ray_per_pixel: usize, window
     Image::new(resolution.clone(), px)
 }
 
+/// The same frame already quantised as `Image::to_png` quantises it (src/image.rs:66-76: c * 255, clamped, truncated),
+/// row-major RGB bytes — what loader3d hands to the PNG encoder, a quarter of the bytes over PCIe.
+pub fn render_rgb8(scene: &GpuScene, resolution: &Vless, ray_per_pixel: usize, window_width: Scalar, camera_eye: Point, projection: Matrix4<Scalar>) -> Vec<u8> {
+    let p = params(resolution, ray_per_pixel, window_width, &camera_eye, &projection);
+    let mut px: Vec<u8> = vec![0u8; (p.width as usize) * (p.height as usize) * 3];
+    if unsafe { nrays_render_rgb8(scene.raw, &p, px.as_mut_ptr()) } != NRAYS_OK {
+        panic!("nrays_render_rgb8: {}", last_error());
+    }
+    px
+}
+
 /// A scene replicated on `num_gpus` GPUs of this node, driven by this one process (framebuffer bands + RCCL exchange
 /// inside the library).
 pub struct GpuSceneSet {
