@@ -66,6 +66,7 @@ struct Builder {
     const std::vector<float>* cent_ptr; // 3 per prim (owned by the root builder)
     std::vector<float> cent_own;
     int max_leaf;
+    float prim_cost = kPrimCost; // an exact f64 ray / triangle test in units of one node visit (SAH leaf criterion)
     int max_depth = 0;
 
     Builder(const std::vector<PrimBounds>& p, std::vector<uint32_t>& o, std::vector<Node2>& n, int ml)
@@ -76,7 +77,7 @@ struct Builder {
         cent_ptr = &cent_own;
     }
     Builder(const Builder& parent, std::vector<Node2>& local) // a task's builder: shares everything but the node array
-        : prims(parent.prims), order(parent.order), nodes(local), cent_ptr(parent.cent_ptr), max_leaf(parent.max_leaf) {}
+        : prims(parent.prims), order(parent.order), nodes(local), cent_ptr(parent.cent_ptr), max_leaf(parent.max_leaf) { prim_cost = parent.prim_cost; }
 
     // Builds the subtree over order[first, first+count); returns its ref and bounds.
     int32_t build(uint32_t first, uint32_t count, Box& bounds, int depth) {
@@ -120,8 +121,8 @@ struct Builder {
         }
         if ((int)count <= max_leaf) {
             // SAH: an exact f64 ray/triangle test costs about kPrimCost times a (two-box, f32) node visit
-            float leaf_cost = bounds.half_area() * (float)count * kPrimCost;
-            float split_cost = best_axis < 0 ? std::numeric_limits<float>::infinity() : best_cost * kPrimCost + bounds.half_area() * 1.0f;
+            float leaf_cost = bounds.half_area() * (float)count * prim_cost;
+            float split_cost = best_axis < 0 ? std::numeric_limits<float>::infinity() : best_cost * prim_cost + bounds.half_area() * 1.0f;
             if (!(split_cost < leaf_cost)) return make_leaf_ref(first, count);
         }
         uint32_t mid;
@@ -219,7 +220,7 @@ struct Collapser {
 
 } // namespace
 
-BuiltBvh build_bvh(const std::vector<PrimBounds>& prims, int max_leaf) {
+BuiltBvh build_bvh(const std::vector<PrimBounds>& prims, int max_leaf, float prim_cost) {
     BuiltBvh out;
     out.max_depth = 0;
     out.order.resize(prims.size());
@@ -229,6 +230,7 @@ BuiltBvh build_bvh(const std::vector<PrimBounds>& prims, int max_leaf) {
     std::vector<Node2> binary;
     binary.reserve(prims.size());
     Builder b(prims, out.order, binary, max_leaf);
+    if (prim_cost > 0.0f) b.prim_cost = prim_cost;
     Box bounds;
     int32_t root2 = b.build(0, (uint32_t)prims.size(), bounds, 0);
     if (root2 < 0) { out.root = root2; return out; } // a single leaf

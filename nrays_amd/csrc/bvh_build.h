@@ -25,7 +25,8 @@ struct BuiltBvh {
 // Leaf ref encoding: ~((first << 3) | (count - 1)), count in [1, 8].
 inline int32_t make_leaf_ref(uint32_t first, uint32_t count) { return ~(int32_t)((first << 3) | (count - 1)); }
 
-BuiltBvh build_bvh(const std::vector<PrimBounds>& prims, int max_leaf);
+// prim_cost: cost of testing one primitive in units of a node visit (SAH leaf criterion); 0 = the default (NR_PRIM_COST)
+BuiltBvh build_bvh(const std::vector<PrimBounds>& prims, int max_leaf, float prim_cost = 0.0f);
 
 // Adds `node_base` to internal child indices and `prim_base` to leaf `first` fields.
 void rebase_bvh(BuiltBvh& bvh, int32_t node_base, uint32_t prim_base);

@@ -209,6 +209,9 @@ static double poly_area2(const ClipPoly& p) { // twice the area of a planar conv
 #ifndef NR_PRESPLIT_HAIRY
 #define NR_PRESPLIT_HAIRY 0.9        // area-weighted emptiness of the mesh above which it counts as hair-like
 #endif
+#ifndef NR_PRIM_COST_HAIRY
+#define NR_PRIM_COST_HAIRY 0.35f
+#endif
 #ifndef NR_PRESPLIT_BUDGET_HAIRY
 #define NR_PRESPLIT_BUDGET_HAIRY 5.0 // re-tuned with the cheaper node step of round 2 (3.0 before): hairball 3.06 -> 2.97 ms, 15.1 -> 11.2 triangle tests per ray; 8.0 gives 2.93 ms for twice the references
 #endif
@@ -285,9 +288,10 @@ static void split_rec(const ClipPoly& poly, const PrimBounds& box, uint32_t tri,
     split_rec(lo, bl, tri, thr, depth + 1, root_slot, slot, out);
     split_rec(hi, bh, tri, thr, depth + 1, root_slot, hi_slot, out);
 }
-static void presplit(const std::vector<TriRec>& recs, std::vector<PrimBounds>& refs_box, std::vector<uint32_t>& refs_tri) {
+// Returns whether the mesh is hair-like (see below).
+static bool presplit(const std::vector<TriRec>& recs, std::vector<PrimBounds>& refs_box, std::vector<uint32_t>& refs_tri) {
     const size_t n = recs.size();
-    if (n < 64 || NR_PRESPLIT_BUDGET <= 0.0) return;
+    if (n < 64 || NR_PRESPLIT_BUDGET <= 0.0) return false;
     double total_area = 0.0;
     for (size_t i = 0; i < n; ++i) total_area += box_half_area(refs_box[i]);
     // Hair-like meshes (most triangles are thin and diagonal: the average box is more than NR_PRESPLIT_HAIRY empty)
@@ -303,7 +307,7 @@ static void presplit(const std::vector<TriRec>& recs, std::vector<PrimBounds>& r
         std::vector<uint32_t> all(n);
         for (size_t i = 0; i < n; ++i) all[i] = (uint32_t)i;
         presplit_heap(recs, all, refs_box, refs_tri, budget, min_gain);
-        return;
+        return hairy;
     }
     // Large meshes: the threshold is measured on every s-th triangle with 1/s of the budget, then all triangles are
     // split against it in parallel.
@@ -330,6 +334,7 @@ static void presplit(const std::vector<TriRec>& recs, std::vector<PrimBounds>& r
     for (const SplitOut& o : outs) extra += o.box.size();
     refs_box.reserve(n + extra); refs_tri.reserve(n + extra);
     for (const SplitOut& o : outs) { refs_box.insert(refs_box.end(), o.box.begin(), o.box.end()); refs_tri.insert(refs_tri.end(), o.tri.begin(), o.tri.end()); }
+    return hairy;
 }
 
 // Appends a BLAS over the triangles of `node_ids` (TriMesh nodes sharing one isometry).
@@ -378,9 +383,11 @@ int append_blas(const NraysSceneDesc* d, const std::vector<uint32_t>& node_ids, 
     std::vector<uint32_t> ref_tri(recs.size());
     for (size_t k = 0; k < ref_tri.size(); ++k) ref_tri[k] = (uint32_t)k;
     auto T0 = std::chrono::steady_clock::now();
-    presplit(recs, pb, ref_tri); // pb becomes one box per REFERENCE
+    const bool hairy = presplit(recs, pb, ref_tri); // pb becomes one box per REFERENCE
     auto T1 = std::chrono::steady_clock::now();
-    BuiltBvh bvh = build_bvh(pb, NR_MAX_LEAF);
+    // thin tubes: a leaf's triangles mostly miss, and a node visit is cheap — leaves split sooner (hairball 2.96 -> 2.91 ms; the
+    // architectural stand-in is 4 % slower with this value, profiles/r02_nodeloop_ab.log)
+    BuiltBvh bvh = build_bvh(pb, NR_MAX_LEAF, hairy ? NR_PRIM_COST_HAIRY : 0.0f);
     auto T2 = std::chrono::steady_clock::now();
     if (getenv("NRAYS_BUILD_TIMES")) fprintf(stderr, "presplit %.2f s, build_bvh %.2f s (%zu refs)\n", std::chrono::duration<double>(T1 - T0).count(), std::chrono::duration<double>(T2 - T1).count(), pb.size());
     if (out.tris.size() + pb.size() >= (1u << 28)) { err = "too many triangles"; return NRAYS_ERR_UNSUPPORTED; }
