@@ -170,7 +170,8 @@ constexpr double kPi = 3.14159265358979323846;
 constexpr double kDblMax = 1.7976931348623157e308;
 
 // ncollide Ball (SURVEY B-4): centre = translation, rotation ignored.
-NR_DEV bool cast_ball(double radius, d3 center, d3 o, d3 d, bool solid, Isect& out) {
+// `record` false: the caller only needs hit / toi (opaque shadow rays) — normal and uv (a square root, three divisions, atan2, asin) are skipped.
+NR_DEV bool cast_ball(double radius, d3 center, d3 o, d3 d, bool solid, bool record, Isect& out) {
     d3 dc = o - center;
     double a = dot(d, d), b = dot(dc, d), c = dot(dc, dc) - radius * radius;
     if (c > 0.0 && b > 0.0) return false;
@@ -180,9 +181,10 @@ NR_DEV bool cast_ball(double radius, d3 center, d3 o, d3 d, bool solid, Isect& o
     double t = (-b - sq) / a;
     bool inside = false;
     if (t <= 0.0) { inside = true; t = solid ? 0.0 : (-b + sq) / a; }
+    out.toi = t;
+    if (!record) return true;
     d3 pos = (o + d * t) - center;
     d3 n = normalize(pos);
-    out.toi = t;
     out.has_uv = true;
     out.u = 0.5 + atan2(n.z, n.x) / (kPi * 2.0);
     out.v = 0.5 - asin(n.y) / kPi;
@@ -445,7 +447,7 @@ NR_DEV void load_xform(const Instance& in, Xform& m) {
 typedef const __attribute__((address_space(1))) Instance* GInstance; // instance record in global memory
 typedef const __attribute__((address_space(3))) Instance* LInstance; // instance record in LDS (kFeatLdsScene kernels)
 template <class P>
-__device__ __forceinline__ Isect cast_analytic_at(P inp, d3 o, d3 d) {
+__device__ __forceinline__ Isect cast_analytic_at(P inp, d3 o, d3 d, bool record) {
     const auto& in = *inp;
     bool solid = (in.flags & kInstSolid) != 0;
     Xform m;
@@ -455,7 +457,7 @@ __device__ __forceinline__ Isect cast_analytic_at(P inp, d3 o, d3 d) {
     Isect out;
     out.toi = 0.0; out.n = D3(0.0, 0.0, 0.0); out.u = 0.0; out.v = 0.0; out.has_uv = false; out.hit = false;
     switch (in.kind) {
-    case NRAYS_SHAPE_BALL: out.hit = cast_ball(in.params[0], m.t, o, d, solid, out); break;
+    case NRAYS_SHAPE_BALL: out.hit = cast_ball(in.params[0], m.t, o, d, solid, record, out); break;
     case NRAYS_SHAPE_CUBOID: out.hit = cast_cuboid(D3(in.params[0], in.params[1], in.params[2]), m, o, d, solid, out); break;
     case NRAYS_SHAPE_CYLINDER: out.hit = cast_cylinder(in.params[0], in.params[1], m, o, d, solid, out); break;
     case NRAYS_SHAPE_CAPSULE: out.hit = cast_capsule(in.params[0], in.params[1], m, o, d, solid, out); break;
@@ -465,13 +467,13 @@ __device__ __forceinline__ Isect cast_analytic_at(P inp, d3 o, d3 d) {
     }
     return out;
 }
-__device__ __noinline__ Isect cast_analytic(GInstance inp, d3 o, d3 d) { return cast_analytic_at(inp, o, d); }
-__device__ __noinline__ Isect cast_analytic_lds(LInstance inp, d3 o, d3 d) { return cast_analytic_at(inp, o, d); }
+__device__ __noinline__ Isect cast_analytic(GInstance inp, d3 o, d3 d, bool record) { return cast_analytic_at(inp, o, d, record); }
+__device__ __noinline__ Isect cast_analytic_lds(LInstance inp, d3 o, d3 d, bool record) { return cast_analytic_at(inp, o, d, record); }
 // The instance records of a kFeatLdsScene kernel live in the workgroup's LDS copy of the scene (k_primary).
 template <int FEAT>
-NR_DEV Isect cast_instance(const Instance& in, d3 o, d3 d) {
-    if (FEAT & kFeatLdsScene) return cast_analytic_lds((LInstance)&in, o, d);
-    return cast_analytic((GInstance)&in, o, d);
+NR_DEV Isect cast_instance(const Instance& in, d3 o, d3 d, bool record = true) {
+    if (FEAT & kFeatLdsScene) return cast_analytic_lds((LInstance)&in, o, d, record);
+    return cast_analytic((GInstance)&in, o, d, record);
 }
 
 // ---------------------------------------------------------------- textures & materials -------
@@ -949,7 +951,7 @@ NR_DEV bool traverse(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, Hit&
         if (kAnalytic) { // TLAS leaf: an analytic shape (or a plane pseudo-leaf)
             const Instance& in = insts[first];
             if (STATS) cnt.prim++;
-            Isect is = cast_instance<FEAT>(in, o, d);
+            Isect is = cast_instance<FEAT>(in, o, d, !(SHADOW && !kAlpha)); // an opaque shadow hit only needs its distance
             if (is.hit && (!GATED || in.kind == NRAYS_SHAPE_PLANE || node_aabb_pass(S, (uint32_t)in.node_id, o, d))) {
                 if (SHADOW) {
                     if (is.toi <= tlimit) {
