@@ -52,7 +52,8 @@ enum InstanceFlags : uint32_t {
     kInstAnyHit = 4u,        // shadow TLAS only: every node behind this BLAS is opaque (alpha == 1
                              // for every hit), so the first hit within maxtoi blocks (scene.rs:328-330)
     kInstHasUv = 8u,         // the mesh(es) behind this BLAS carry uvs
-    kInstNoXform = 16u       // identity rotation AND zero translation: local space == world space
+    kInstNoXform = 16u,      // identity rotation AND zero translation: local space == world space
+    kInstNoUvValues = 32u    // the node's material never reads the VALUES of u, v (NormalMaterial, untextured Phong): a ball skips atan2 / asin
 };
 
 // Flags carried in the 3 low bits of a TLAS leaf ref (triangle leaves use them as count - 1).

@@ -462,7 +462,7 @@ int build_host_scene(const NraysSceneDesc* d, HostScene& out, std::string& err) 
     }
 
     // ---- per-node records, opacity classification, transform groups ----------------------
-    struct NodeInfo { double R[9]; bool identity; bool opaque; bool has_uv; };
+    struct NodeInfo { double R[9]; bool identity; bool opaque; bool has_uv; bool no_uv_values; };
     std::vector<NodeInfo> info(d->num_nodes);
     float att_min = std::numeric_limits<float>::infinity();
     for (uint32_t i = 0; i < d->num_nodes; ++i) {
@@ -474,6 +474,7 @@ int build_host_scene(const NraysSceneDesc* d, HostScene& out, std::string& err) 
         const NraysMaterial& m = d->materials[n.material_id];
         bool has_uv = n.shape_kind == NRAYS_SHAPE_TRIMESH ? d->meshes[n.mesh_id].uvs != nullptr : shape_has_uv(n.shape_kind);
         info[i].has_uv = has_uv;
+        info[i].no_uv_values = m.kind == NRAYS_MAT_NORMAL || (m.kind == NRAYS_MAT_PHONG && m.texture_id < 0 && m.alpha_texture_id < 0);
         // ambiant().w is 1 for NormalMaterial, 1/0 for UVMaterial with/without uvs, and the alpha
         // map's w (or 1) for PhongMaterial; a node blocks shadow rays iff w * node.alpha >= 1 (scene.rs:322-331).
         bool w_is_one = m.kind == NRAYS_MAT_NORMAL || (m.kind == NRAYS_MAT_UV && has_uv) ||
@@ -534,7 +535,7 @@ int build_host_scene(const NraysSceneDesc* d, HostScene& out, std::string& err) 
         for (int k = 0; k < 9; ++k) in.rot[k] = info[ni].R[k];
         for (int k = 0; k < 3; ++k) { in.trans[k] = n.translation[k]; in.params[k] = n.params[k]; }
         in.kind = n.shape_kind;
-        in.flags = (n.solid ? kInstSolid : 0u) | (info[ni].identity ? kInstIdentityRot : 0u) | (info[ni].has_uv ? kInstHasUv : 0u);
+        in.flags = (n.solid ? kInstSolid : 0u) | (info[ni].identity ? kInstIdentityRot : 0u) | (info[ni].has_uv ? kInstHasUv : 0u) | (info[ni].no_uv_values ? kInstNoUvValues : 0u);
         if (info[ni].identity && n.translation[0] == 0.0 && n.translation[1] == 0.0 && n.translation[2] == 0.0) in.flags |= kInstNoXform;
         in.node_id = (int32_t)ni; in.blas_root = kEmptyChild;
         return in;

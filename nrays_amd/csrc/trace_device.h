@@ -170,8 +170,9 @@ constexpr double kPi = 3.14159265358979323846;
 constexpr double kDblMax = 1.7976931348623157e308;
 
 // ncollide Ball (SURVEY B-4): centre = translation, rotation ignored.
-// `record` false: the caller only needs hit / toi (opaque shadow rays) — normal and uv (a square root, three divisions, atan2, asin) are skipped.
-NR_DEV bool cast_ball(double radius, d3 center, d3 o, d3 d, bool solid, bool record, Isect& out) {
+// `record`: 0 = the caller only needs hit / toi (opaque shadow rays), 1 = and the normal (materials that never read the values of u, v:
+// kInstNoUvValues), 2 = everything.  What is left out — a square root and three divisions, atan2 and asin — is never looked at.
+NR_DEV bool cast_ball(double radius, d3 center, d3 o, d3 d, bool solid, int record, Isect& out) {
     d3 dc = o - center;
     double a = dot(d, d), b = dot(dc, d), c = dot(dc, dc) - radius * radius;
     if (c > 0.0 && b > 0.0) return false;
@@ -186,9 +187,10 @@ NR_DEV bool cast_ball(double radius, d3 center, d3 o, d3 d, bool solid, bool rec
     d3 pos = (o + d * t) - center;
     d3 n = normalize(pos);
     out.has_uv = true;
+    out.n = inside ? -n : n;
+    if (record < 2) return true;
     out.u = 0.5 + atan2(n.z, n.x) / (kPi * 2.0);
     out.v = 0.5 - asin(n.y) / kPi;
-    out.n = inside ? -n : n;
     return true;
 }
 
@@ -457,7 +459,7 @@ __device__ __forceinline__ Isect cast_analytic_at(P inp, d3 o, d3 d, bool record
     Isect out;
     out.toi = 0.0; out.n = D3(0.0, 0.0, 0.0); out.u = 0.0; out.v = 0.0; out.has_uv = false; out.hit = false;
     switch (in.kind) {
-    case NRAYS_SHAPE_BALL: out.hit = cast_ball(in.params[0], m.t, o, d, solid, record, out); break;
+    case NRAYS_SHAPE_BALL: out.hit = cast_ball(in.params[0], m.t, o, d, solid, !record ? 0 : ((in.flags & kInstNoUvValues) ? 1 : 2), out); break;
     case NRAYS_SHAPE_CUBOID: out.hit = cast_cuboid(D3(in.params[0], in.params[1], in.params[2]), m, o, d, solid, out); break;
     case NRAYS_SHAPE_CYLINDER: out.hit = cast_cylinder(in.params[0], in.params[1], m, o, d, solid, out); break;
     case NRAYS_SHAPE_CAPSULE: out.hit = cast_capsule(in.params[0], in.params[1], m, o, d, solid, out); break;
