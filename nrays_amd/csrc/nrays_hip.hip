@@ -701,6 +701,7 @@ static void launch_primary(bool instrumented, int features, uint32_t grid, hipSt
     // plain frames (tables, no RNG keys, one sample per pixel) of the analytic-only permutations
     const bool plain = R.col_tab && !R.use_rng && R.first_batch && R.sample_begin == 0u && R.sample_end == 1u;
 #define NR_LAUNCH_PLAIN(F) hipLaunchKernelGGL((k_primary<false, F, true>), dim3(grid), dim3(kBlock), 0, stream, d, R, qo, out, ctr, spill, tx, ty, work, grab, zero_counts, zero_ctr)
+#ifndef NR_ONLY_MESH // tuning builds: only the mesh permutations (everything else renders with the full kernel)
     if (plain && features == 33) { NR_LAUNCH_PLAIN(33); return; }
     if (plain && features == 37) { NR_LAUNCH_PLAIN(37); return; }
     if (plain && features == 49) { NR_LAUNCH_PLAIN(49); return; }
@@ -709,29 +710,32 @@ static void launch_primary(bool instrumented, int features, uint32_t grid, hipSt
     if (plain && features == 5) { NR_LAUNCH_PLAIN(5); return; }
     if (plain && features == 17) { NR_LAUNCH_PLAIN(17); return; }
     if (plain && features == 21) { NR_LAUNCH_PLAIN(21); return; }
+#endif
     if (plain && features == 2) { NR_LAUNCH_PLAIN(2); return; }
     if (plain && features == 6) { NR_LAUNCH_PLAIN(6); return; }
     if (plain && features == 18) { NR_LAUNCH_PLAIN(18); return; }
     if (plain && features == 22) { NR_LAUNCH_PLAIN(22); return; }
 #undef NR_LAUNCH_PLAIN
     switch (features) { // bit 8 (double branching) only in the full kernels; bit 16 = multi-sample lighting
+#ifndef NR_ONLY_MESH
     case 33: NR_LAUNCH(33); break; // 1, 5, 17, 21 with the scene records in LDS
     case 37: NR_LAUNCH(37); break;
     case 49: NR_LAUNCH(49); break;
     case 53: NR_LAUNCH(53); break;
     case 1: NR_LAUNCH(1); break;
-    case 2: NR_LAUNCH(2); break;
     case 3: NR_LAUNCH(3); break;
     case 5: NR_LAUNCH(5); break;
-    case 6: NR_LAUNCH(6); break;
     case 7: NR_LAUNCH(7); break;
     case 15: NR_LAUNCH(15); break;
     case 17: NR_LAUNCH(17); break;
-    case 18: NR_LAUNCH(18); break;
     case 19: NR_LAUNCH(19); break;
     case 21: NR_LAUNCH(21); break;
-    case 22: NR_LAUNCH(22); break;
     case 23: NR_LAUNCH(23); break;
+#endif
+    case 2: NR_LAUNCH(2); break;
+    case 6: NR_LAUNCH(6); break;
+    case 18: NR_LAUNCH(18); break;
+    case 22: NR_LAUNCH(22); break;
     default: NR_LAUNCH(31); break;
     }
 #undef NR_LAUNCH

@@ -28,7 +28,10 @@
 namespace nrays {
 
 constexpr int kBlock = 256;     // threads per workgroup = 4 wave64 (8-wave workgroups measured slower: 100 vs 86 us on balls)
-constexpr int kLdsStack = 32;   // traversal-stack entries kept in LDS per lane (then spills to HBM)
+#ifndef NR_LDS_STACK
+#define NR_LDS_STACK 32
+#endif
+constexpr int kLdsStack = NR_LDS_STACK;   // traversal-stack entries kept in LDS per lane (then spills to HBM)
 constexpr int32_t kSentinel = (int32_t)0x80000001; // marks "leave the BLAS" on the traversal stack
 
 #define NR_DEV __device__ __forceinline__
