@@ -35,6 +35,9 @@ constexpr int kLdsStack = NR_LDS_STACK;   // traversal-stack entries kept in LDS
 constexpr int32_t kSentinel = (int32_t)0x80000001; // marks "leave the BLAS" on the traversal stack
 
 #define NR_DEV __device__ __forceinline__
+#ifndef NR_SCALAR_NODES
+#define NR_SCALAR_NODES 1 // wave-uniform node visits fetch the node with scalar loads (traverse())
+#endif
 
 // Kernel permutations by scene content (decided once per scene on the host): a scene only pays, in
 // registers and instructions, for the code paths it can reach.
@@ -143,6 +146,7 @@ struct Stack {
             // issues a generic flat_load
             int32_t v = (int32_t)*(volatile lds_u32*)&lds[(n < kLdsStack ? n : kLdsStack - 1) * kBlock];
             if (n >= kLdsStack) v = (int32_t)spill[(size_t)(n - kLdsStack) * spill_stride];
+            asm volatile("" : "+v"(v)); // the value is complete HERE: the callers' join points then carry no pending vector load (their wait would also cover the node prefetches)
             return v;
         }
         return (int32_t)*top;
@@ -636,6 +640,31 @@ NR_DEV NodePlanes load_planes(const BvhNode* nodes, int32_t node, const RayF& r)
 }
 NR_DEV int4 load_children(const BvhNode* nodes, int32_t node) { return *(const int4*)((const char*)nodes + (((uint32_t)node << 7) | 32u)); }
 
+// The same fetch for a visit in which EVERY active lane of the wave sits on the same node with the same direction signs (`ukey` =
+// node << 7 | RayF::bits, wave-uniform): seven scalar loads through the scalar data cache into SGPRs — no vector-memory request, no
+// bytes through the vector L1's return path (the shared ceiling of the node loops: a vector fetch moves 112 bytes PER LANE), no VGPRs;
+// the slab arithmetic then reads the planes as scalar operands.  8x8-pixel packets of primary rays, the shadow rays of a tile towards
+// one point light and the samples of one pixel spend most of their visits like this.
+typedef float fx4 __attribute__((ext_vector_type(4)));
+typedef int ix4 __attribute__((ext_vector_type(4)));
+NR_DEV float4 F4(fx4 v) { float4 r; r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w; return r; }
+NR_DEV NodePlanes load_planes_uniform(const BvhNode* nodes, uint32_t ukey) {
+    const __attribute__((address_space(4))) char* base = (const __attribute__((address_space(4))) char*)(uintptr_t)nodes;
+    const uint32_t at = ukey & ~127u;
+    const uint32_t ax = at | (ukey & 16u), ay = at | (ukey & 32u), az = at | (ukey & 64u);
+    NodePlanes p;
+    p.xn = F4(*(const __attribute__((address_space(4))) fx4*)(base + ax)); p.xf = F4(*(const __attribute__((address_space(4))) fx4*)(base + (ax ^ 16u)));
+    p.yn = F4(*(const __attribute__((address_space(4))) fx4*)(base + ay + 64)); p.yf = F4(*(const __attribute__((address_space(4))) fx4*)(base + (ay ^ 32u) + 64));
+    p.zn = F4(*(const __attribute__((address_space(4))) fx4*)(base + az + 48)); p.zf = F4(*(const __attribute__((address_space(4))) fx4*)(base + (az ^ 64u) + 48));
+    return p;
+}
+NR_DEV int4 load_children_uniform(const BvhNode* nodes, uint32_t ukey) {
+    const __attribute__((address_space(4))) char* base = (const __attribute__((address_space(4))) char*)(uintptr_t)nodes;
+    const ix4 c = *(const __attribute__((address_space(4))) ix4*)(base + ((ukey & ~127u) | 32u));
+    int4 r; r.x = c.x; r.y = c.y; r.z = c.z; r.w = c.w;
+    return r;
+}
+
 // Four boxes at once: sort keys k = entry distance (>= 0) of a child the ray may enter before `tbest`, +inf for a child
 // it cannot (absent children hold an inverted box and always get +inf).  Two children per packed-f32 instruction.
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -836,18 +865,30 @@ NR_DEV bool traverse(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, Hit&
     for (;;) {
         NR_TOC(cyc_leaf, tphase);
         while (cur >= 0) {
-            const NodePlanes np = load_planes(S.nodes, cur, rf);
-            const int4 ch = load_children(S.nodes, cur);
             NR_ITER(wv_node, ln_node);
             NR_UNIFORM(cur);
-            // SURVEY 8d counts AABB tests: only the boxes that exist (an absent child slot is not a test)
-            if (STATS) cnt.node += (unsigned)(ch.x != kEmptyChild) + (unsigned)(ch.y != kEmptyChild) + (unsigned)(ch.z != kEmptyChild) + (unsigned)(ch.w != kEmptyChild);
             // sort keys: entry distance, +inf for a child the ray cannot enter (absent children always: inverted boxes)
             const float kMiss = __builtin_inff();
             float k0, k1, k2, k3;
-            box_keys4(np, rf, btf, k0, k1, k2, k3);
-            if ((rf.bits & 7u)) zero_axis_cull((rf.bits & 7u), co, np, k0, k1, k2, k3);
-            int32_t c0 = ch.x, c1 = ch.y, c2 = ch.z, c3 = ch.w;
+            int32_t c0, c1, c2, c3;
+            const uint32_t nkey = ((uint32_t)cur << 7) | rf.bits;
+            const uint32_t ukey = (uint32_t)__builtin_amdgcn_readfirstlane((int)nkey);
+            if (NR_SCALAR_NODES && kMesh && __ballot(nkey != ukey) == 0ULL) { // wave-uniform: the active lanes share the node and the direction signs
+                const int4 ch = load_children_uniform(S.nodes, ukey);
+                const NodePlanes np = load_planes_uniform(S.nodes, ukey);
+                // SURVEY 8d counts AABB tests: only the boxes that exist (an absent child slot is not a test)
+                if (STATS) cnt.node += (unsigned)(ch.x != kEmptyChild) + (unsigned)(ch.y != kEmptyChild) + (unsigned)(ch.z != kEmptyChild) + (unsigned)(ch.w != kEmptyChild);
+                box_keys4(np, rf, btf, k0, k1, k2, k3);
+                if ((rf.bits & 7u)) zero_axis_cull((rf.bits & 7u), co, np, k0, k1, k2, k3);
+                c0 = ch.x; c1 = ch.y; c2 = ch.z; c3 = ch.w;
+            } else {
+                const int4 ch = load_children(S.nodes, cur);
+                const NodePlanes np = load_planes(S.nodes, cur, rf);
+                if (STATS) cnt.node += (unsigned)(ch.x != kEmptyChild) + (unsigned)(ch.y != kEmptyChild) + (unsigned)(ch.z != kEmptyChild) + (unsigned)(ch.w != kEmptyChild);
+                box_keys4(np, rf, btf, k0, k1, k2, k3);
+                if ((rf.bits & 7u)) zero_axis_cull((rf.bits & 7u), co, np, k0, k1, k2, k3);
+                c0 = ch.x; c1 = ch.y; c2 = ch.z; c3 = ch.w;
+            }
             if (!SHADOW) {
                 // closest hit: 5-comparator sorting network on (key, ref), ascending entry distance;
                 // farthest first onto the stack, nearest becomes the next node
