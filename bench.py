@@ -14,16 +14,23 @@ scaling: the frame is fixed).  Rank 0 prints ONE JSON line.  (`--gpus N` without
 
 At N = 1 the line also carries
   roofline       contract fields (achieved = algorithmic bytes / kernel time against the 8 TB/s HBM peak) PLUS what
-                 actually bounds the kernel: dram_frac (counter bytes / time / peak), valu_active_frac, fp64_issue_frac,
-                 l2_gbs, compulsory_bytes — from rocprofv3 --pmc passes run live by this script (traffic_source says
-                 whether the counters are live or replayed from profiles/);
+                 actually bounds the kernel: `bound` / `limiter` (longest wave tile vs sum of tile cycles per resident
+                 wave, from the library's per-tile cycle counts), dram_frac, valu_active_frac, wave_wait_frac,
+                 fp64_issue_frac, l2_gbs, compulsory_bytes — from rocprofv3 --pmc passes run live by this script
+                 (traffic_source says whether the counters are live or replayed from profiles/);
+  scene_build_s, cold_frame_ms, moving_camera_ms_per_frame   what a caller pays besides the resting-camera steady state
+                 the contract's loop times (the reference's only caller renders each camera ONCE);
+  value_traced   the rate on the rays that went through a BVT query (wave tiles outside the scene's screen bounds are
+                 written without one);
   cpu_baseline   the oracle (a port of the reference algorithm) on all host cores, scene built before the clock starts;
-  secondary      the crytek_sponza stand-in (BASELINE config 3, the north star's >= 100x target) with its own
-                 roofline and cpu_baseline blocks.
+  secondary      the crytek_sponza stand-in (BASELINE config 3, the north star's >= 100x target) and the hairball
+                 stand-in with their own roofline and cpu_baseline blocks; at N > 1 BASELINE config 4 (3840x2160,
+                 8 lights), the frame that can scale.
 """
 import argparse
 import ctypes as C
 import json
+import math
 import os
 import sys
 import time
@@ -43,7 +50,7 @@ CYCLES_PER_F64_TRANS_WAVE_INSTR = 5.2
 
 
 def load_workload(name):
-    """Returns (scene object with .descriptor / .device_handle(), camera dict, description)."""
+    """Returns (scene object with .descriptor / .device_handle(), camera dict, description with %d x %d for the resolution)."""
     if name == "balls":
         from tools import gen_assets
         from nrays_amd import scenefile
@@ -51,9 +58,13 @@ def load_workload(name):
         fs = scenefile.FileScene(os.path.join(ROOT, "scenes", "balls.scene"))
         cam = fs.camera_dict()
         return fs, cam, "scenes/balls.scene via the loader3d front-end, %dx%d, refl 0.2 0.25 (4 reflection bounces), 1 ray/pixel, procedural globe.png"
-    from tests import standins
-    sc, cam = standins.sponza_scene()
-    return sc, cam, "crytek_sponza STAND-IN (procedural, %d triangles, 276 nodes, alpha-mapped foliage; the real asset is not shipped upstream), " % standins.SPONZA_TRIS + "%dx%d, 1 light, 1 ray/pixel"
+    from tools import standins
+    if name == "hairball":
+        sc, cam = standins.hairball_scene()
+        return sc, cam, "hairball STAND-IN (procedural, 2.88 M triangles: 3000 strands x 8 sides x 60 segments; the real asset is not shipped upstream), %dx%d, 1 light, 1 ray/pixel"
+    sc, cam = standins.sponza_scene(n_lights=8 if name == "config4" else 1)
+    return sc, cam, "crytek_sponza STAND-IN (procedural, %d triangles, 276 nodes, alpha-mapped foliage; the real asset is not shipped upstream), " % standins.SPONZA_TRIS + (
+        "%dx%d, 8 lights (BASELINE config 4), 1 ray/pixel" if name == "config4" else "%dx%d, 1 light, 1 ray/pixel")
 
 
 def camera_params(cam, W, H):
@@ -63,24 +74,38 @@ def camera_params(cam, W, H):
     return nr.make_params((W, H), 1, 0.0, cam["eye"], proj)
 
 
-def roofline_block(pk, tst, W, owned_rows, scene_bytes, pmc, pmc_source):
-    """SURVEY 8d roofline of the dominant kernel (k_primary) + the bounds that actually hold."""
+def roofline_block(pk, tst, W, owned_rows, scene_bytes, pmc, pmc_source, tile_costs=None):
+    """SURVEY 8d roofline of the dominant kernel (k_primary): the contract fields (achieved = algorithmic bytes / kernel time
+    against the HBM peak) plus what the counters say actually bounds it: `bound` names the measured limiter
+    and `limiter.frac` is the kernel time that limiter accounts for."""
     bytes_primary = pk.algorithmic_bytes(W, owned_rows)
     t = tst.kernel_ms_primary * 1e-3
     achieved = bytes_primary / t / 1e9 if t > 0 else 0.0
     fb = 12 * W * owned_rows
-    r = {"bound": "hbm", "kernel": "k_primary", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    r = {"bound": "hbm", "contract_bound": "hbm", "kernel": "k_primary", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "traffic_source": None,
          "algorithmic_bytes_per_launch": int(bytes_primary), "kernel_ms": round(tst.kernel_ms_primary, 5),
          "frame_gpu_ms": round(tst.kernel_ms_total, 5), "launches_timed": int(tst.frames_timed),
          "compulsory_bytes": int(scene_bytes + fb),
          "units_per_launch": {"rays": int(pk.total_rays()), "node_tests": int(pk.node_tests), "tri_tests": int(pk.tri_tests),
                               "prim_tests": int(pk.prim_tests), "hit_records": int(pk.hit_records), "tex_samples": int(pk.tex_samples)},
-         "note": "frac = algorithmic record bytes (SURVEY 8d formula, AABB tests counted per existing child box) / kernel time / "
-                 "HBM peak: a rate of useful bytes, NOT a DRAM utilisation — the scene is cache-resident, see dram_frac. Tiles the "
-                 "scene's screen bounds decide cost no box test, so culling LOWERS this fraction while the frame gets faster. What "
-                 "bounds the kernel (DESIGN.md 5): analytic frames the latency of their longest tile's dependent chain, mesh frames "
-                 "VALU issue of the node loop at two waves per SIMD (valu_active_frac)"}
+         "note": "achieved / frac = algorithmic record bytes (SURVEY 8d formula; every primary ray counts its root-box tests, as the "
+                 "reference would run them) / kernel time / HBM peak: a rate of useful record bytes, NOT a DRAM utilisation — the "
+                 "scenes are cache-resident (dram_frac) and most node fetches are scalar loads since round 3. `bound` is the "
+                 "measured limiter: the persistent kernel cannot end before its longest 8x8 wave tile does (one pixel chain of "
+                 "dependent traversals) nor before sum-of-tile-cycles / resident waves have passed (limiter block)"}
+    if tile_costs is not None and t > 0 and tile_costs.tiles:
+        # shader cycles -> seconds at the guide's 2.4 GHz maximum (the clock under load is lower: the fractions are lower bounds)
+        longest = tile_costs.max_cycles / CLOCK_HZ
+        through = tile_costs.sum_cycles / max(tile_costs.resident_waves, 1) / CLOCK_HZ
+        lim = {"longest_tile_cycles": int(tile_costs.max_cycles), "sum_tile_cycles": int(tile_costs.sum_cycles), "wave_tiles": int(tile_costs.tiles),
+               "resident_waves": int(tile_costs.resident_waves), "longest_tile_frac": round(longest / t, 4),
+               "wave_throughput_frac": round(through / t, 4),
+               "source": "nrays_get_tile_costs: s_memtime cycles of every wave tile of this camera's cost-recording frame"}
+        lim["name"] = "latency/longest-tile" if longest >= through else "throughput/wave-cycles"
+        lim["frac"] = round(max(longest, through) / t, 4)
+        r["bound"] = lim["name"]
+        r["limiter"] = lim
     if pmc and t > 0:
         r["traffic_source"] = pmc_source
         if pmc.get("hbm_bytes_per_launch") is not None:
@@ -89,12 +114,16 @@ def roofline_block(pk, tst, W, owned_rows, scene_bytes, pmc, pmc_source):
         simd_cycles = NUM_SIMDS * t * CLOCK_HZ
         if pmc.get("SQ_ACTIVE_INST_VALU") is not None:  # quad-cycles summed over waves
             r["valu_active_frac"] = round(4.0 * pmc["SQ_ACTIVE_INST_VALU"] / simd_cycles, 4)
+        if pmc.get("SQ_WAIT_ANY") is not None and pmc.get("SQ_WAVE_CYCLES"):
+            r["wave_wait_frac"] = round(pmc["SQ_WAIT_ANY"] / pmc["SQ_WAVE_CYCLES"], 4)  # share of the waves' lifetime spent in s_waitcnt
         f64 = [pmc.get(k) for k in ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_TRANS_F64")]
         if all(v is not None for v in f64):
             r["f64_wave_instructions"] = int(sum(f64))
             r["fp64_issue_frac"] = round((sum(f64[:3]) * CYCLES_PER_F64_WAVE_INSTR + f64[3] * CYCLES_PER_F64_TRANS_WAVE_INSTR) / simd_cycles, 4)
         if pmc.get("SQ_INSTS_VALU") is not None:
             r["valu_wave_instructions"] = int(pmc["SQ_INSTS_VALU"])
+        if pmc.get("SQ_INSTS_VMEM_RD") is not None:
+            r["vector_load_wave_instructions"] = int(pmc["SQ_INSTS_VMEM_RD"])
         if pmc.get("TCC_HIT_sum") is not None and pmc.get("TCC_MISS_sum") is not None:
             req = pmc["TCC_HIT_sum"] + pmc["TCC_MISS_sum"]
             r["l2_hit_rate"] = round(pmc["TCC_HIT_sum"] / max(req, 1.0), 4)
@@ -114,12 +143,13 @@ def pmc_for(workload, W, H, live):
                 return res, "live: rocprofv3 --pmc (2 passes, tools/pmc_collect.py TRAFFIC_PASSES) on tools/kbench.py --child %s in this run" % workload
         except Exception as e:  # the bench line must not depend on the profiler
             print("live PMC collection failed: %r" % (e,), file=sys.stderr)
-    path = os.path.join(ROOT, "profiles", "r02_pmc_%s.json" % workload)
-    if os.path.exists(path) and (W, H) == (1920, 1080):
-        try:
-            return json.load(open(path)), "replayed from profiles/r02_pmc_%s.json (python tools/pmc_collect.py %s ...; not measured in this run)" % (workload, workload)
-        except Exception:
-            pass
+    for rnd in ("r03", "r02"):
+        path = os.path.join(ROOT, "profiles", "%s_pmc_%s.json" % (rnd, workload))
+        if os.path.exists(path) and (W, H) == (1920, 1080):
+            try:
+                return json.load(open(path)), "replayed from profiles/%s_pmc_%s.json (python tools/pmc_collect.py %s ...; not measured in this run)" % (rnd, workload, workload)
+            except Exception:
+                pass
     return None, None
 
 
@@ -127,23 +157,32 @@ def cpu_baseline(scene, params, budget_s):
     """The CPU leg: the oracle (a port of the reference algorithm: f64, best-first two-level BVT, recursive trace) on
     all host cores with the reference's static pixel partition (scene.rs:49-66).  The BVTs are built before the clock
     starts (Scene::new is outside scene::render, loader3d.rs:57-93), the threads are created once and each renders its
-    range `reps` times; the sample is sized to at least ~1.5 s of wall time (10-30 CPU-seconds and more on a many-core
-    host), at most `budget_s`."""
+    range `reps` times.  The sample is sized from a WARM call (the first one pays thread start-up and page faults) to at
+    least 1.5 s of wall time — 10-30 CPU-seconds and far more on a many-core host — and at most `budget_s`."""
     import oracle  # the checker, used here only as the timed CPU baseline
     cores = os.cpu_count() or 1
-    sec, st = oracle.render_timed(scene.descriptor, params, cores, 1)
-    reps = int(max(1, min(4096, 1.5 / max(sec, 1e-4), budget_s / max(sec, 1e-4))))
-    if reps > 1:
+    oracle.render_timed(scene.descriptor, params, cores, 1)            # cold: not used
+    sec, st = oracle.render_timed(scene.descriptor, params, cores, 1)  # warm: sizes the sample
+    per_frame, reps, spent = sec, 1, 2.0 * sec
+    while sec < 1.5 and reps < 8192 and spent < budget_s:
+        want = int(math.ceil(1.8 / max(per_frame, 1e-5)))                       # frames for ~1.8 s
+        afford = int((budget_s - spent) / max(per_frame, 1e-5))                # frames the budget still pays for
+        new_reps = max(reps + 1, min(8192, want, max(afford, 1)))
+        if new_reps <= reps:
+            break
+        reps = new_reps
         sec, st = oracle.render_timed(scene.descriptor, params, cores, reps)
+        spent += sec
+        per_frame = sec / reps
     rays = max(st.total_rays(), 1)
-    sample = "%d x full %dx%d frame, %d rays, %.2f s wall on %d persistent threads (%.0f CPU-s), BVT build excluded" % (
+    sample = "%d x full %dx%d frame, %d rays, %.2f s wall on %d persistent threads (%.0f CPU-s), BVT build excluded, sized from a warm call" % (
         reps, params.width, params.height, rays, sec, cores, sec * cores)
     # SURVEY 8d: the same rays through the reference-equivalent tree (median split, one primitive per leaf, best-first
     # search), reported beside the shipped BVH's counts in roofline.units_per_launch
     ref_counts = {"aabb_tests_per_ray": round(st.node_tests / rays, 2), "tri_tests_per_ray": round(st.tri_tests / rays, 2),
                   "prim_tests_per_ray": round(st.prim_tests / rays, 3)}
     return {"value": round(rays / sec / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port", "sample": sample,
-            "reference_tree_counts": ref_counts}
+            "sample_seconds": round(sec, 3), "reference_tree_counts": ref_counts}
 
 
 def reference_toolchain_probe():
@@ -155,52 +194,100 @@ def reference_toolchain_probe():
             "rust_reference_timed": False}
 
 
-def single_gpu_measure(name, W, H, steps, warmup, args):
-    """One workload on the current device: instrumented frame (counts), timed loop, roofline, CPU baseline."""
+def single_gpu_measure(name, W, H, steps, warmup, args, pmc=True, moving=True):
+    """One workload on the current device: what a caller gets on a fresh handle (scene build, cold first frame), the
+    steady-state loop the contract times, a moving-camera figure, roofline + limiter, CPU baseline."""
     import torch
     import nrays_amd as nr
     from nrays_amd import abi
     lib = abi.load_hip_lib()
-    scene, cam, desc = load_workload(name)
-    p = camera_params(cam, W, H)
-    handle = scene.device_handle()
-    out = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
+    out = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
 
-    def render(instrumented=False):
+    def render_on(handle, params, instrumented=False):
         fn = lib.nrays_render_device_instrumented if instrumented else lib.nrays_render_device
-        abi.check(fn(handle, C.byref(p), C.c_void_p(out.data_ptr()), C.c_void_p(stream)))
+        abi.check(fn(handle, C.byref(params), C.c_void_p(out.data_ptr()), C.c_void_p(stream)))
 
-    render(True)
+    # (1) process warm-up on a throw-away handle: the first launch of a kernel in a process loads its code object
+    warm_scene, cam, desc = load_workload(name)
+    p = camera_params(cam, W, H)
+    render_on(warm_scene.device_handle(), p)
+    torch.cuda.synchronize()
+    del warm_scene
+    # (2) what a drop-in scene::render delivers for ONE render of a camera (loader3d.rs:67-93 renders each camera once):
+    # Scene::new -> nrays_scene_create (flatten, BVH build, upload), then the FIRST frame of the fresh handle — no cost
+    # history (image-order work lists), cost recording on, raygen tables built, per-handle buffers allocated
+    scene, cam, desc = load_workload(name)
+    t0 = time.perf_counter()
+    handle = scene.device_handle()
+    torch.cuda.synchronize()
+    scene_build_s = time.perf_counter() - t0
+    first = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        render_on(handle, p)
+        torch.cuda.synchronize()
+        first.append((time.perf_counter() - t0) * 1e3)
+
+    render_on(handle, p, True)
     st = nr.get_stats(scene)
     pk = abi.NraysStats()
     abi.check(lib.nrays_get_primary_kernel_stats(handle, C.byref(pk)))
-    # untimed, before the contract's warmup: the library settles its per-camera scheduling state in three plain frames of a
-    # resting camera (tile costs recorded -> sorted -> occupancy / order decided; pixels never depend on it), so the
-    # measured steps are steady-state frames whatever --warmup says
-    for _ in range(4):
-        render()
+    # (3) the contract's loop.  Untimed, before --warmup: the library settles its per-camera scheduling state in three plain
+    # frames of a resting camera (tile costs recorded -> sorted -> order decided; pixels never depend on it), so the timed
+    # steps are RESTING-CAMERA STEADY-STATE frames whatever --warmup says (cold_frame_ms / moving_camera_ms_per_frame are the others)
+    settle = 4
+    for _ in range(settle):
+        render_on(handle, p)
     torch.cuda.synchronize()
+    tile_costs = abi.NraysTileCosts()
+    if lib.nrays_get_tile_costs(handle, C.byref(tile_costs)) != 0:
+        tile_costs = None
     for _ in range(warmup):
-        render()
+        render_on(handle, p)
     nr.get_stats(scene)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        render()
+        render_on(handle, p)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     tst = nr.get_stats(scene)
-    pmc, src = (None, None) if args.no_pmc else pmc_for(name, W, H, live=not args.replay_pmc)
+    plain = st  # the instrumented frame's counters: rays_primary_traced (what reached a BVT query) is only counted there
     res = {"workload": desc % (W, H), "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 5),
            "value": round(st.total_rays() * steps / dt / 1e6, 3), "unit": "Mrays/s",
+           "steady_state": "resting camera: %d untimed settle frames before --warmup (per-camera cost order decided); kernel_ms from HIP events on every 4th frame" % settle,
            "rays_per_frame": {"total": int(st.total_rays()), "primary": int(st.rays_primary), "reflection": int(st.rays_reflection),
                               "refraction": int(st.rays_refraction), "shadow": int(st.rays_shadow)},
-           "roofline": roofline_block(pk, tst, W, H, lib.nrays_scene_device_bytes(handle), pmc, src)}
+           # rays that went through a BVT query: the wave tiles the scene's screen bounds or the root test decide write the
+           # background without one (same pixels; the reference would have queried) — the rate on them is the honest traversal rate
+           "rays_traced_per_frame": int(plain.rays_traced()),
+           "value_traced": round(plain.rays_traced() * steps / dt / 1e6, 3),
+           "scene_build_s": round(scene_build_s, 4),
+           "cold_frame_ms": round(first[0], 4), "second_frame_ms": round(first[1], 4), "third_frame_ms": round(first[2], 4),
+           "cold_frame_note": "fresh handle in a warm process (kernels loaded): first scene::render of a camera — no cost history, cost "
+                              "recording, raygen tables, per-handle buffer allocation; host-synchronised wall time"}
+    if moving:
+        # a camera that moves every frame (eye shifted by 1e-3 of its distance per frame): cost recording + re-sorting stay on
+        import numpy as np
+        eye0 = np.array(cam["eye"], dtype=np.float64); at = np.array(cam["at"], dtype=np.float64)
+        frames = max(10, min(steps, 40))
+        params = [camera_params(dict(cam, eye=tuple(eye0 + (k + 1) * 1e-3 * np.linalg.norm(eye0 - at) * np.array([1.0, 0.0, 0.0]))), W, H) for k in range(frames)]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for q in params:
+            render_on(handle, q)
+        torch.cuda.synchronize()
+        res["moving_camera_ms_per_frame"] = round((time.perf_counter() - t0) / frames * 1e3, 5)
+    pmc_res, src = (None, None) if (args.no_pmc or not pmc) else pmc_for(name, W, H, live=not args.replay_pmc)
+    res["roofline"] = roofline_block(pk, tst, W, H, lib.nrays_scene_device_bytes(handle), pmc_res, src, tile_costs)
     if not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(scene, p, args.cpu_seconds)
         res["gpu_over_cpu"] = round(res["value"] / max(res["cpu_baseline"]["value"], 1e-9), 1)
     return res
+
+
+WORKLOAD_RES = {"config4": (3840, 2160)}  # BASELINE config 4: crytek_sponza 3840x2160, 8 lights
 
 
 def main():
@@ -208,15 +295,19 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--scene", default="balls", choices=["balls", "sponza"])
+    ap.add_argument("--width", type=int, default=0, help="default: 1920 (3840 for --scene config4)")
+    ap.add_argument("--height", type=int, default=0, help="default: 1080 (2160 for --scene config4)")
+    ap.add_argument("--scene", default="balls", choices=["balls", "sponza", "hairball", "config4"],
+                    help="balls = BASELINE config 2 (the metric's workload); config4 = crytek_sponza stand-in 3840x2160 with 8 lights")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the sponza stand-in block")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary blocks (sponza / hairball stand-ins; config 4 at N > 1)")
     ap.add_argument("--no-pmc", action="store_true", help="no hardware counters at all (traffic: null)")
     ap.add_argument("--replay-pmc", action="store_true", help="take the counters from profiles/ instead of running rocprofv3")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall-time cap of each CPU-baseline leg")
     args = ap.parse_args()
+    dw, dh = WORKLOAD_RES.get(args.scene, (1920, 1080))
+    args.width = args.width or dw
+    args.height = args.height or dh
 
     import torch
     import torch.distributed as dist
@@ -253,29 +344,38 @@ def main():
     return result
 
 
+METRIC = "Mrays/s (primary+shadow+reflection), 1920x1080, 4 bounces"
+
+
 def run_single(args):
     W, H = args.width, args.height
     m = single_gpu_measure(args.scene, W, H, args.steps, args.warmup, args)
     result = {
-        "metric": "Mrays/s (primary+shadow+reflection), 1920x1080, 4 bounces",
+        "metric": METRIC,
         "value": m["value"], "unit": "Mrays/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": m["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": m["workload"], "resolution": [W, H], "ray_per_pixel": 1, "parallelism": "1 GPU",
-                   "rays_per_frame": m["rays_per_frame"]},
+                   "rays_per_frame": m["rays_per_frame"], "rays_traced_per_frame": m["rays_traced_per_frame"],
+                   "steady_state": m["steady_state"]},
+        "value_traced": m["value_traced"],
+        "scene_build_s": m["scene_build_s"], "cold_frame_ms": m["cold_frame_ms"], "second_frame_ms": m["second_frame_ms"],
+        "third_frame_ms": m["third_frame_ms"], "cold_frame_note": m["cold_frame_note"],
+        "moving_camera_ms_per_frame": m.get("moving_camera_ms_per_frame"),
         "roofline": m["roofline"],
     }
     if "cpu_baseline" in m:
         result["cpu_baseline"] = m["cpu_baseline"]
     if args.scene == "balls" and not args.no_secondary:
-        # BASELINE config 3 / the north star's ">= 100x CPU on crytek_sponza at 1 GPU": same process, same run
-        s = single_gpu_measure("sponza", W, H, max(10, min(args.steps, 60)), max(3, min(args.warmup, 10)), args)
-        result["secondary"] = {"sponza_standin": s}
+        # BASELINE config 3 / the north star's ">= 100x CPU on crytek_sponza at 1 GPU", and the hairball (BVH stress): same process, same run
+        sec_steps, sec_warm = max(10, min(args.steps, 60)), max(3, min(args.warmup, 10))
+        result["secondary"] = {"sponza_standin": single_gpu_measure("sponza", W, H, sec_steps, sec_warm, args),
+                               "hairball_standin": single_gpu_measure("hairball", W, H, max(10, min(args.steps, 30)), sec_warm, args, pmc=False, moving=False)}
     result["reference_toolchain"] = reference_toolchain_probe()
     return result
 
 
-def run_tiled(args, rank, world, owners):
+def tiled_measure(name, W, H, steps, warmup, rank, world, owners):
     """N > 1 through the library's own multi-GPU path (nrays_render_multi_device, multi_gpu.cpp): band
     tiling, grouped RCCL send / receive to owner 0, k_untile — one C call per frame and rank, no Python in the step.
       world > 1   one process per GPU (torch.distributed.run): rank r drives owner r; torch.distributed only ships the
@@ -287,8 +387,7 @@ def run_tiled(args, rank, world, owners):
     import nrays_amd as nr
     from nrays_amd import abi, tiling
     lib = abi.load_hip_lib()
-    W, H = args.width, args.height
-    scene, cam, desc = load_workload(args.scene)
+    scene, cam, desc = load_workload(name)
     full = camera_params(cam, W, H)
     if world > 1:
         uid = torch.zeros(abi.UNIQUE_ID_BYTES, dtype=torch.uint8, device="cuda")
@@ -325,19 +424,22 @@ def run_tiled(args, rank, world, owners):
         ss.render_device(full, fptr)
     ss.sync()
     st = ss.stats()
+    tile_costs = abi.NraysTileCosts()
+    if lib.nrays_get_tile_costs(h0, C.byref(tile_costs)) != 0:
+        tile_costs = None
     rays_t = torch.tensor([st.total_rays(), st.rays_primary, st.rays_reflection, st.rays_refraction, st.rays_shadow],
                           dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(rays_t)
     rays_total = float(rays_t[0].item())
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         ss.render_device(full, fptr)
     ss.sync()
     ss.stats()  # drains the event rings so that the averages below cover the timed steps only
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         ss.render_device(full, fptr)
     ss.sync()  # every frame is rendered, exchanged and un-permuted on owner 0 before the clock stops
     barrier()
@@ -354,23 +456,41 @@ def run_tiled(args, rank, world, owners):
         abi.check(lib.nrays_render_device(scene.device_handle(), C.byref(full), C.c_void_p(direct.data_ptr()), None))
         torch.cuda.synchronize()
         check = bool(torch.equal(direct, frame))
-    result = None
+        abi.check(lib.nrays_render_device_instrumented(scene.device_handle(), C.byref(full), C.c_void_p(direct.data_ptr()), None))
+        traced = nr.get_stats(scene).rays_traced()  # counted by instrumented renders only
+    res = None
     if rank == 0:
         owned = len(tiling.owned_rows(H, band, owner0, owners))
-        result = {
-            "metric": "Mrays/s (primary+shadow+reflection), 1920x1080, 4 bounces",
-            "value": round(rays_total * args.steps / dt / 1e6, 3), "unit": "Mrays/s", "n_gpus": owners, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": desc % (W, H), "resolution": [W, H], "ray_per_pixel": 1, "parallelism": mode,
-                       "tiled_frame_identical_to_single_gpu_render": check,
-                       "rays_per_frame": {"total": int(rays_total), "primary": int(rays_t[1].item()), "reflection": int(rays_t[2].item()),
-                                          "refraction": int(rays_t[3].item()), "shadow": int(rays_t[4].item())}},
-            # owner 0's tile kernel; no counters at N > 1 (the profiler leg runs at N = 1 only)
-            "roofline": roofline_block(pk, tst, W, owned, lib.nrays_scene_device_bytes(h0), None, None),
-        }
+        res = {"value": round(rays_total * steps / dt / 1e6, 3), "unit": "Mrays/s", "steps": steps, "warmup": warmup,
+               "ms_per_step": round(dt / steps * 1e3, 5), "value_traced": round(traced * steps / dt / 1e6, 3),
+               "config": {"workload": desc % (W, H), "resolution": [W, H], "ray_per_pixel": 1, "parallelism": mode,
+                          "tiled_frame_identical_to_single_gpu_render": check,
+                          "rays_per_frame": {"total": int(rays_total), "primary": int(rays_t[1].item()), "reflection": int(rays_t[2].item()),
+                                             "refraction": int(rays_t[3].item()), "shadow": int(rays_t[4].item())},
+                          "rays_traced_per_frame": int(traced)},
+               # owner 0's tile kernel; no counters at N > 1 (the profiler leg runs at N = 1 only)
+               "roofline": roofline_block(pk, tst, W, owned, lib.nrays_scene_device_bytes(h0), None, None, tile_costs)}
     ss.close()
     lib.nrays_comm_destroy(comm)
+    return res
+
+
+def run_tiled(args, rank, world, owners):
+    W, H = args.width, args.height
+    m = tiled_measure(args.scene, W, H, args.steps, args.warmup, rank, world, owners)
+    # the frame DESIGN.md 6 names as the one to tile (the metric's balls frame takes 0.05 ms on one GPU: the worst possible
+    # strong-scaling workload): BASELINE config 4, reported beside the contract's line at every N > 1
+    sec = None
+    if args.scene == "balls" and not args.no_secondary:
+        cw, ch = WORKLOAD_RES["config4"]
+        sec = tiled_measure("config4", cw, ch, max(5, min(args.steps, 20)), max(2, min(args.warmup, 5)), rank, world, owners)
+    if rank != 0:
+        return None
+    result = {"metric": METRIC, "value": m["value"], "unit": "Mrays/s", "n_gpus": owners, "steps": args.steps, "warmup": args.warmup,
+              "ms_per_step": m["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+              "dtype": "f64", "data": "synthetic", "config": m["config"], "value_traced": m["value_traced"], "roofline": m["roofline"]}
+    if sec is not None:
+        result["secondary"] = {"config4_sponza_standin_4k_8_lights": sec}
     return result
 
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define NRAYS_ABI_VERSION 1
+#define NRAYS_ABI_VERSION 2
 
 typedef enum NraysStatus {
     NRAYS_OK = 0,
@@ -185,6 +185,9 @@ typedef struct NraysStats {
     uint32_t frames_timed;    /* renders averaged in the two figures above (since the previous get_stats): the events
                                  are recorded on every 4th render of a handle and on every instrumented one */
     uint32_t reserved;
+    uint64_t rays_primary_traced; /* instrumented renders only: primary rays that went through a BVT query: rays_primary minus the ones whose wave tile was
+                                     decided without one (outside the scene's screen bounds, or no ray of the tile passes the
+                                     root of the BVT) — the pixels are the same, the reference would have queried for them */
 } NraysStats;
 
 /* Threading contract of a scene handle: the library is re-entrant on DISTINCT handles (any threads, any streams).
@@ -235,6 +238,35 @@ int nrays_get_stats(NraysScene* scene, NraysStats* out_stats);
  * primary rays, the shadow rays they spawned and the traversal work of both — the per-launch units
  * behind bench.py's roofline figure. */
 int nrays_get_primary_kernel_stats(NraysScene* scene, NraysStats* out_stats);
+
+/* Per-wave-tile cost of the last frame that recorded it (the first frames of a camera record the shader cycles every 8x8-pixel
+ * wave tile took, for the cost-ordered work lists): the two numbers that bound a frame of the persistent kernel — it cannot end
+ * before its LONGEST tile does (a pixel's chain of dependent traversals), nor before sum / resident_waves cycles have passed. */
+typedef struct NraysTileCosts {
+    uint64_t tiles;          /* wave tiles recorded */
+    uint64_t sum_cycles;     /* shader cycles (s_memtime) over all of them */
+    uint64_t max_cycles;     /* the longest tile */
+    uint64_t resident_waves; /* waves of the persistent grid that rendered the frame */
+} NraysTileCosts;
+int nrays_get_tile_costs(NraysScene* scene, NraysTileCosts* out);
+
+/* Probe of the two BVT queries of the path on caller-supplied rays — the device intersectors and traversals WITHOUT raygen and
+ * shading around them, so that fixtures derived independently of this code base (tests/golden/kat_independent.npz) can be
+ * checked against the HIP path directly.
+ *   mode 0  Scene::trace's closest-hit query (src/scene.rs:164-166) + SceneNode::cast's record (src/scene_node.rs:51-54):
+ *           flags bit 0 = hit, bit 1 = the record carries uvs; toi, world normal, uv, scene-node index.
+ *   mode 1  Scene::intersects_ray (src/scene.rs:147-161) with `max_toi[i]`: flags bit 0 = blocked by an opaque node;
+ *           normal[0..2] = the colour filter of the transparent nodes crossed (1, 1, 1 if none).
+ * `origins` / `dirs`: n x 3 doubles, `max_toi`: n doubles (mode 1 only), `out`: n records; all HOST memory.  Blocking. */
+typedef struct NraysCastResult {
+    double toi;
+    double normal[3];
+    double uv[2];
+    int32_t node_id;
+    uint32_t flags;
+} NraysCastResult;
+int nrays_debug_cast_batch(NraysScene* scene, uint32_t mode, uint32_t n, const double* origins, const double* dirs,
+                           const double* max_toi, NraysCastResult* out);
 
 /* Device bytes of the flattened scene (BVH nodes, triangle records, instance / shading records, textures): what
  * a frame must read at least once — the compulsory part of bench.py's roofline block. */

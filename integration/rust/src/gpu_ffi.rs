@@ -144,6 +144,26 @@ pub struct NraysStats {
     pub kernel_ms_total: f64,
     pub frames_timed: u32,
     pub reserved: u32,
+    pub rays_primary_traced: u64,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct NraysTileCosts {
+    pub tiles: u64,
+    pub sum_cycles: u64,
+    pub max_cycles: u64,
+    pub resident_waves: u64,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct NraysCastResult {
+    pub toi: f64,
+    pub normal: [f64; 3],
+    pub uv: [f64; 2],
+    pub node_id: i32,
+    pub flags: u32,
 }
 
 pub enum NraysScene {}
@@ -165,6 +185,8 @@ extern "C" {
     pub fn nrays_untile_device(gathered: *const f32, out_rgb_device: *mut f32, width: u32, height: u32, band_rows: u32, band_owners: u32, hip_stream: *mut c_void) -> c_int;
     pub fn nrays_get_stats(scene: *mut NraysScene, out_stats: *mut NraysStats) -> c_int;
     pub fn nrays_get_primary_kernel_stats(scene: *mut NraysScene, out_stats: *mut NraysStats) -> c_int;
+    pub fn nrays_get_tile_costs(scene: *mut NraysScene, out: *mut NraysTileCosts) -> c_int;
+    pub fn nrays_debug_cast_batch(scene: *mut NraysScene, mode: u32, n: u32, origins: *const f64, dirs: *const f64, max_toi: *const f64, out: *mut NraysCastResult) -> c_int;
 
     pub fn nrays_comm_unique_id(out_id: *mut u8) -> c_int;
     pub fn nrays_comm_create(id: *const u8, num_ranks: u32, rank: u32, out_comm: *mut *mut NraysComm) -> c_int;

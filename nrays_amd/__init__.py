@@ -6,4 +6,4 @@ front-end (host/), and this thin ctypes mirror of the reference's scene-model su
 from . import abi  # noqa: F401
 from .scene import (Ball, Capsule, Cone, Cuboid, Cylinder, ImageData, Interpolation, Isometry3, Light,  # noqa: F401
                     NormalMaterial, Overflow, PhongMaterial, Plane, Scene, SceneDescriptor, SceneNode, Texture2d,
-                    TriMesh, UVMaterial, get_stats, make_params, render)
+                    TriMesh, UVMaterial, cast_rays, get_stats, make_params, render, shadow_rays)

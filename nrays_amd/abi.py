@@ -6,7 +6,7 @@ and types must match include/nrays_abi.h exactly (tests/test_abi.py checks sizes
 import ctypes as C
 import os
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # NraysStatus
 OK = 0
@@ -75,7 +75,12 @@ class NraysStats(C.Structure):
                 ("rays_shadow", C.c_uint64), ("node_tests", C.c_uint64), ("tri_tests", C.c_uint64),
                 ("prim_tests", C.c_uint64), ("hit_records", C.c_uint64), ("tex_samples", C.c_uint64),
                 ("generations", C.c_uint32), ("instrumented", C.c_uint32), ("kernel_ms_primary", C.c_double),
-                ("kernel_ms_total", C.c_double), ("frames_timed", C.c_uint32), ("reserved", C.c_uint32)]
+                ("kernel_ms_total", C.c_double), ("frames_timed", C.c_uint32), ("reserved", C.c_uint32),
+                ("rays_primary_traced", C.c_uint64)]
+
+    def rays_traced(self):
+        """Rays that went through a BVT query (total_rays() counts every primary ray the reference would trace)."""
+        return self.rays_primary_traced + self.rays_reflection + self.rays_refraction + self.rays_shadow
 
     def total_rays(self):
         return self.rays_primary + self.rays_reflection + self.rays_refraction + self.rays_shadow
@@ -90,8 +95,19 @@ class NraysStats(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+class NraysTileCosts(C.Structure):
+    _fields_ = [("tiles", C.c_uint64), ("sum_cycles", C.c_uint64), ("max_cycles", C.c_uint64), ("resident_waves", C.c_uint64)]
+
+
+class NraysCastResult(C.Structure):
+    _fields_ = [("toi", C.c_double), ("normal", C.c_double * 3), ("uv", C.c_double * 2), ("node_id", C.c_int32), ("flags", C.c_uint32)]
+
+
 # Every symbol include/nrays_abi.h declares, with its ctypes signature.
 HIP_SYMBOLS = {
+    "nrays_get_tile_costs": (C.c_int, [C.c_void_p, C.POINTER(NraysTileCosts)]),
+    "nrays_debug_cast_batch": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                         C.POINTER(NraysCastResult)]),
     "nrays_scene_create": (C.c_int, [C.POINTER(NraysSceneDesc), C.POINTER(C.c_void_p)]),
     "nrays_render": (C.c_int, [C.c_void_p, C.POINTER(NraysRenderParams), C.POINTER(C.c_float)]),
     "nrays_render_rgb8": (C.c_int, [C.c_void_p, C.POINTER(NraysRenderParams), C.POINTER(C.c_uint8)]),

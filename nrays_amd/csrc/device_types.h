@@ -132,6 +132,7 @@ struct LightRec { // src/light.rs:8-13
 // counters are only touched by the instrumented kernel variants).
 struct DeviceCounters {
     unsigned long long rays_reflection, rays_refraction, rays_shadow;
+    unsigned long long rays_primary_traced; // primary rays whose wave tile entered the trace loop (not decided by the screen bounds / the root test)
     unsigned long long node_tests, tri_tests, prim_tests, hit_records, tex_samples;
     unsigned int overflow;  // set when a continuation queue ran out of capacity
     unsigned int max_depth; // deepest trace depth reached (= number of continuation generations)

@@ -67,6 +67,9 @@ struct NraysComm {
     // one communicator per DISTINCT local device (local mode) or the process's single communicator (ranked mode)
     std::vector<int> comm_devices;
     std::vector<ncclComm_t> comms;
+    // A failure inside a grouped RCCL call leaves the peers' matching operations without a partner: the communicators are aborted
+    // and every later call on this group fails fast with NRAYS_ERR_RCCL instead of hanging.
+    bool poisoned = false;
     int comm_index_of_device(int dev) const {
         for (size_t i = 0; i < comm_devices.size(); ++i) if (comm_devices[i] == dev) return (int)i;
         return -1;
@@ -146,8 +149,16 @@ int nrays_comm_create_local(uint32_t num_owners, const int32_t* devices, NraysCo
     return NRAYS_OK;
 }
 
+static void poison(NraysComm* c) { // ncclCommAbort releases the communicator: nothing is left to destroy afterwards
+    if (c->poisoned) return;
+    c->poisoned = true;
+    for (size_t i = 0; i < c->comms.size(); ++i) { (void)hipSetDevice(c->comm_devices[i]); (void)ncclCommAbort(c->comms[i]); }
+    c->comms.clear();
+}
+
 void nrays_comm_destroy(NraysComm* c) {
     if (!c) return;
+    DeviceGuard guard;
     for (size_t i = 0; i < c->comms.size(); ++i) { (void)hipSetDevice(c->comm_devices[i]); (void)ncclCommDestroy(c->comms[i]); }
     delete c;
 }
@@ -255,6 +266,7 @@ int nrays_render_multi_device(NraysSceneSet* s, const NraysRenderParams* params,
     if (s->has_root() && !out_rgb_device) return nrays::set_last_error(NRAYS_ERR_BAD_ARG, "owner 0 needs an output buffer");
     if (params->width == 0 || params->height == 0 || params->ray_per_pixel == 0) return nrays::set_last_error(NRAYS_ERR_BAD_ARG, "bad render parameters");
     NraysComm* c = s->comm;
+    if (c->poisoned) return nrays::set_last_error(NRAYS_ERR_RCCL, "the communicator was aborted after a failed exchange: destroy the scene set and the communicator");
     const uint32_t owners = c->owners;
     DeviceGuard guard;
     int rc = ensure_buffers(s, params);
@@ -295,25 +307,35 @@ int nrays_render_multi_device(NraysSceneSet* s, const NraysRenderParams* params,
         }
         if (any_rccl && !c->comms.empty()) {
             MG_NCCL(ncclGroupStart());
+            // Between ncclGroupStart and ncclGroupEnd nothing may return: the first failure is remembered, the group is ALWAYS
+            // closed, and a failed exchange aborts the communicators (poison) so that neither a retry nor the peers hang.
+            int group_rc = NRAYS_OK; std::string group_msg;
+            auto hip_ok = [&](hipError_t e, const char* what) { if (e != hipSuccess && group_rc == NRAYS_OK) { group_rc = NRAYS_ERR_HIP; group_msg = std::string(what) + ": " + hipGetErrorString(e); } return e == hipSuccess; };
+            auto nccl_ok = [&](ncclResult_t r, const char* what) { if (r != ncclSuccess && group_rc == NRAYS_OK) { group_rc = NRAYS_ERR_RCCL; group_msg = std::string(what) + ": " + ncclGetErrorString(r); } return r == ncclSuccess; };
             if (c->ranked) {
                 if (c->rank == 0) {
-                    for (uint32_t r = 1; r < owners; ++r)
-                        MG_NCCL(ncclRecv(s->gathered[slot] + (size_t)r * count, count, ncclFloat, (int)r, c->comms[0], root->comm_stream));
+                    for (uint32_t r = 1; r < owners && group_rc == NRAYS_OK; ++r)
+                        nccl_ok(ncclRecv(s->gathered[slot] + (size_t)r * count, count, ncclFloat, (int)r, c->comms[0], root->comm_stream), "ncclRecv");
                 } else {
-                    MG_NCCL(ncclSend(s->local[0].tile[slot], count, ncclFloat, 0, c->comms[0], s->local[0].comm_stream));
+                    nccl_ok(ncclSend(s->local[0].tile[slot], count, ncclFloat, 0, c->comms[0], s->local[0].comm_stream), "ncclSend");
                 }
             } else {
                 const int root_ci = c->comm_index_of_device(root_dev);
                 for (auto& o : s->local) {
                     if (o.index == 0 || o.device == root_dev) continue;
+                    if (group_rc != NRAYS_OK) break;
                     const int ci = c->comm_index_of_device(o.device);
-                    MG_HIP(hipSetDevice(o.device));
-                    MG_NCCL(ncclSend(o.tile[slot], count, ncclFloat, root_ci, c->comms[ci], o.comm_stream));
-                    MG_HIP(hipSetDevice(root_dev));
-                    MG_NCCL(ncclRecv(s->gathered[slot] + (size_t)o.index * count, count, ncclFloat, ci, c->comms[root_ci], root->comm_stream));
+                    if (!hip_ok(hipSetDevice(o.device), "hipSetDevice")) break;
+                    if (!nccl_ok(ncclSend(o.tile[slot], count, ncclFloat, root_ci, c->comms[ci], o.comm_stream), "ncclSend")) break;
+                    if (!hip_ok(hipSetDevice(root_dev), "hipSetDevice")) break;
+                    if (!nccl_ok(ncclRecv(s->gathered[slot] + (size_t)o.index * count, count, ncclFloat, ci, c->comms[root_ci], root->comm_stream), "ncclRecv")) break;
                 }
             }
-            MG_NCCL(ncclGroupEnd());
+            nccl_ok(ncclGroupEnd(), "ncclGroupEnd");
+            if (group_rc != NRAYS_OK) {
+                poison(c);
+                return nrays::set_last_error(group_rc, group_msg + " (exchange aborted; the communicator is no longer usable)");
+            }
         }
         for (auto& o : s->local) { // tile[slot] may be rendered into again once its copy / send is done
             MG_HIP(hipSetDevice(o.device));
@@ -386,7 +408,7 @@ int nrays_multi_get_stats(NraysSceneSet* s, NraysStats* out) {
         if (rc != NRAYS_OK) return rc;
         out->rays_primary += st.rays_primary; out->rays_reflection += st.rays_reflection; out->rays_refraction += st.rays_refraction;
         out->rays_shadow += st.rays_shadow; out->node_tests += st.node_tests; out->tri_tests += st.tri_tests; out->prim_tests += st.prim_tests;
-        out->hit_records += st.hit_records; out->tex_samples += st.tex_samples;
+        out->hit_records += st.hit_records; out->tex_samples += st.tex_samples; out->rays_primary_traced += st.rays_primary_traced;
         out->generations = std::max(out->generations, st.generations);
         if (k == 0) { out->kernel_ms_primary = st.kernel_ms_primary; out->kernel_ms_total = st.kernel_ms_total; out->frames_timed = st.frames_timed; out->instrumented = st.instrumented; }
     }

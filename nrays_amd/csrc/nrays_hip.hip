@@ -9,8 +9,9 @@
 //               raygen -> [no ray of the tile passes the root box: background] -> closest hit -> Phong + shadow
 //               rays -> continuation kept in registers (trace_chain) -> pixel write.  Only the second child of a
 //               hit that spawns a reflection AND a refraction goes to the compacted HBM queue (wave ballots).
-//   k_bounce    rounds over that queue (double-branching scenes only): same per-ray work, atomicAdd of the weighted
-//               contribution into the pixel, second children appended to the next round's queue.
+//   k_bounce    rounds over that queue (double-branching scenes only): same per-ray work, the weighted contribution added to
+//               the pixel's 64-bit fixed-point sum (order-independent), second children appended to the next round's queue;
+//   k_fold_fixed  adds those sums to the frame after the rounds of a sample batch.
 //   k_resolve   divides by ray_per_pixel when it is > 1 (scene.rs:94).
 //   k_untile    un-permutes gathered multi-GPU tile buffers.
 #include <hip/hip_runtime.h>
@@ -66,13 +67,13 @@ __device__ __forceinline__ uint32_t issue_grab(uint32_t* work_counters, uint32_t
 __device__ __forceinline__ void flush_counters(DeviceCounters* ctr, const Cnt& c, bool stats) {
     // wave-level reduction, then one atomic per wave and class
     unsigned sh = c.shadow, rl = c.refl, rf = c.refr, md = c.max_depth, mc = c.max_chain_nodes;
-    unsigned nd = c.node, tr = c.tri, pr = c.prim, ht = c.hit, tx = c.tex;
+    unsigned nd = c.node, tr = c.tri, pr = c.prim, ht = c.hit, tx = c.tex, tc = c.traced;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         sh += __shfl_down(sh, off); rl += __shfl_down(rl, off); rf += __shfl_down(rf, off);
         unsigned om = __shfl_down(md, off); md = om > md ? om : md;
         if (stats) { unsigned oc = __shfl_down(mc, off); mc = oc > mc ? oc : mc; }
-        if (stats) { nd += __shfl_down(nd, off); tr += __shfl_down(tr, off); pr += __shfl_down(pr, off); ht += __shfl_down(ht, off); tx += __shfl_down(tx, off); }
+        if (stats) { nd += __shfl_down(nd, off); tr += __shfl_down(tr, off); pr += __shfl_down(pr, off); ht += __shfl_down(ht, off); tx += __shfl_down(tx, off); tc += __shfl_down(tc, off); }
     }
 #ifdef NR_PHASE_TIMING
     unsigned pn = c.cyc_node, pl = c.cyc_leaf, pt = c.cyc_tri; // accumulators only advance in active lanes: take the max over the wave
@@ -104,6 +105,7 @@ __device__ __forceinline__ void flush_counters(DeviceCounters* ctr, const Cnt& c
             atomicAdd(&ctr->node_tests, (unsigned long long)nd); atomicAdd(&ctr->tri_tests, (unsigned long long)tr);
             atomicAdd(&ctr->prim_tests, (unsigned long long)pr); atomicAdd(&ctr->hit_records, (unsigned long long)ht);
             atomicAdd(&ctr->tex_samples, (unsigned long long)tx);
+            if (tc) atomicAdd(&ctr->rays_primary_traced, (unsigned long long)tc);
         }
     }
 }
@@ -184,7 +186,7 @@ __global__ void __launch_bounds__(kBlock, waves_per_simd(FEAT)) k_primary(DScene
     st.spill = spill ? (global_u32*)(spill + (size_t)blockIdx.x * kBlock + threadIdx.x) : nullptr;
     st.lds0 = Stack::addr((lds_u32*)lds_stack);
     st.init();
-    Cnt cnt; cnt.node = cnt.tri = cnt.prim = cnt.hit = cnt.tex = cnt.shadow = cnt.refl = cnt.refr = cnt.max_depth = cnt.max_chain_nodes = 0;
+    Cnt cnt; cnt.node = cnt.tri = cnt.prim = cnt.hit = cnt.tex = cnt.shadow = cnt.refl = cnt.refr = cnt.max_depth = cnt.max_chain_nodes = cnt.traced = 0;
 #ifdef NR_PHASE_TIMING
     cnt.cyc_node = cnt.cyc_leaf = cnt.cyc_other = cnt.cyc_tri = 0; cnt.wv_node = cnt.ln_node = cnt.wv_tri = cnt.ln_tri = 0; cnt.cyc_closest0 = cnt.cyc_closestN = cnt.cyc_shadow = 0; cnt.wv_uni = 0;
     unsigned long long twave = __builtin_readcyclecounter();
@@ -333,8 +335,12 @@ __global__ void __launch_bounds__(kBlock, waves_per_simd(FEAT)) k_primary(DScene
                 // no ray of this wave tile gets past the root of the BVT: Scene::trace returns the background for
                 // all of them (scene.rs:157-161), without entering the trace loop
                 c = F3(S.background[0], S.background[1], S.background[2]);
+                // (tiles the screen bounds decide run no box test at all: node_tests excludes them)
                 if (STATS && !tile_misses && sample_active && S.closest_root >= 0) cnt.node += root_children(S);
             } else {
+                // instrumented renders only: a uniform counter in the tile loop of the plain kernels costs 25 us of the 52 us balls
+                // frame (profiles/r03 notes)
+                if (STATS && sample_active) cnt.traced++;
                 c = trace_chain<STATS, FEAT>(S, st, sample_active, ray, 0u, R.max_depth, qo, cnt, !PLAIN && R.use_rng != 0u);
             }
             if (STATS) { unsigned dn = cnt.node - node_before; if (dn > cnt.max_chain_nodes) cnt.max_chain_nodes = dn; }
@@ -375,9 +381,22 @@ __global__ void __launch_bounds__(kBlock, waves_per_simd(FEAT)) k_primary(DScene
     flush_counters(ctr, cnt, STATS);
 }
 
+__device__ __forceinline__ long long to_fixed(float x) {
+    double v = (double)x * 4294967296.0;
+    v = v > 9.0e18 ? 9.0e18 : (v < -9.0e18 ? -9.0e18 : v); // (NaN -> 0 below)
+    return v == v ? __double2ll_rn(v) : 0ll;
+}
+// out += fixed-point sums of the queued chains (k_bounce), which are cleared for the next sample batch.
+__global__ void k_fold_fixed(float* __restrict__ out, long long* __restrict__ fixed, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const long long f = fixed[i];
+    if (f != 0ll) { out[i] = out[i] + (float)((double)f * (1.0 / 4294967296.0)); fixed[i] = 0ll; }
+}
+
 template <bool STATS>
 __global__ void __launch_bounds__(kBlock, NRAYS_WAVES_PER_SIMD) k_bounce(DScene S, RayQueue qin, const uint32_t* __restrict__ count_in, uint32_t capacity,
-                                                    QueueOut qo, float* __restrict__ out, DeviceCounters* ctr, uint32_t* spill,
+                                                    QueueOut qo, long long* __restrict__ fixed, DeviceCounters* ctr, uint32_t* spill,
                                                     uint32_t max_depth) {
     __shared__ uint32_t lds_stack[kLdsStack * kBlock];
     Stack st;
@@ -386,7 +405,7 @@ __global__ void __launch_bounds__(kBlock, NRAYS_WAVES_PER_SIMD) k_bounce(DScene 
     st.spill = spill ? (global_u32*)(spill + (size_t)blockIdx.x * kBlock + threadIdx.x) : nullptr;
     st.lds0 = Stack::addr((lds_u32*)lds_stack);
     st.init();
-    Cnt cnt; cnt.node = cnt.tri = cnt.prim = cnt.hit = cnt.tex = cnt.shadow = cnt.refl = cnt.refr = cnt.max_depth = cnt.max_chain_nodes = 0;
+    Cnt cnt; cnt.node = cnt.tri = cnt.prim = cnt.hit = cnt.tex = cnt.shadow = cnt.refl = cnt.refr = cnt.max_depth = cnt.max_chain_nodes = cnt.traced = 0;
 #ifdef NR_PHASE_TIMING
     cnt.cyc_node = cnt.cyc_leaf = cnt.cyc_other = cnt.cyc_tri = 0; cnt.wv_node = cnt.ln_node = cnt.wv_tri = cnt.ln_tri = 0; cnt.cyc_closest0 = cnt.cyc_closestN = cnt.cyc_shadow = 0; cnt.wv_uni = 0;
 #endif
@@ -401,11 +420,56 @@ __global__ void __launch_bounds__(kBlock, NRAYS_WAVES_PER_SIMD) k_bounce(DScene 
         if (active) queue_load(qin, idx, ray, depth);
         f3 c = trace_chain<STATS, kFeatAll>(S, st, active, ray, depth, max_depth, qo, cnt, true);
         if (active) {
-            float* o = out + (size_t)ray.pixel * 3;
-            unsafeAtomicAdd(o, c.x); unsafeAtomicAdd(o + 1, c.y); unsafeAtomicAdd(o + 2, c.z);
+            // The queued chains of a pixel finish in no particular order.  Their contributions are therefore summed as 64-bit
+            // FIXED-POINT numbers (2^-32 units: integer addition is associative, so the sum does not depend on the order) and
+            // folded into the frame by k_fold_fixed once the rounds of the batch are over: frames of double-branching scenes are
+            // bit-reproducible.  The 2.3e-10 quantum is far below the f32 resolution of a pixel value.
+            unsigned long long* f = (unsigned long long*)(fixed + (size_t)ray.pixel * 3);
+            atomicAdd(f, (unsigned long long)to_fixed(c.x)); atomicAdd(f + 1, (unsigned long long)to_fixed(c.y)); atomicAdd(f + 2, (unsigned long long)to_fixed(c.z));
         }
     }
     flush_counters(ctr, cnt, STATS);
+}
+
+// nrays_debug_cast_batch: the closest-hit query with the deferred exact gates exactly as shade_hit runs it (ungated traversal, the
+// winner checked against the reference's AABB gates, fully gated repeat for knife-edge rays), or the shadow query, on rays from memory.
+__global__ void __launch_bounds__(kBlock, NRAYS_WAVES_PER_SIMD) k_cast_batch(DScene S, uint32_t mode, uint32_t n, const double* __restrict__ ro, const double* __restrict__ rd,
+                                                                              const double* __restrict__ max_toi, NraysCastResult* __restrict__ out, uint32_t* spill) {
+    __shared__ uint32_t lds_stack[kLdsStack * kBlock];
+    Stack st;
+    st.lds = (lds_u32*)(lds_stack + threadIdx.x);
+    st.spill_stride = gridDim.x * kBlock;
+    st.spill = spill ? (global_u32*)(spill + (size_t)blockIdx.x * kBlock + threadIdx.x) : nullptr;
+    st.lds0 = Stack::addr((lds_u32*)lds_stack);
+    st.init();
+    Cnt cnt; cnt.node = cnt.tri = cnt.prim = cnt.hit = cnt.tex = cnt.shadow = cnt.refl = cnt.refr = cnt.max_depth = cnt.max_chain_nodes = cnt.traced = 0;
+#ifdef NR_PHASE_TIMING
+    cnt.cyc_node = cnt.cyc_leaf = cnt.cyc_other = cnt.cyc_tri = 0; cnt.wv_node = cnt.ln_node = cnt.wv_tri = cnt.ln_tri = 0; cnt.cyc_closest0 = cnt.cyc_closestN = cnt.cyc_shadow = 0; cnt.wv_uni = 0;
+#endif
+    for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
+        const uint32_t i = base + threadIdx.x;
+        if (i >= n) continue;
+        const d3 o = D3(ro[3 * (size_t)i], ro[3 * (size_t)i + 1], ro[3 * (size_t)i + 2]), d = D3(rd[3 * (size_t)i], rd[3 * (size_t)i + 1], rd[3 * (size_t)i + 2]);
+        NraysCastResult r; r.toi = 0.0; r.normal[0] = r.normal[1] = r.normal[2] = 0.0; r.uv[0] = r.uv[1] = 0.0; r.node_id = -1; r.flags = 0u;
+        Hit hit; f3 filter = F3(1.0f, 1.0f, 1.0f);
+        if (mode == 1u) {
+            const bool blocked = traverse<true, false, kFeatAll>(S, st, o, d, max_toi[i], hit, filter, cnt);
+            r.flags = blocked ? 1u : 0u; r.normal[0] = filter.x; r.normal[1] = filter.y; r.normal[2] = filter.z;
+        } else {
+            Isect is; uint32_t node_id = 0; bool gated = false, any = false;
+            for (;;) {
+                any = traverse<false, false, kFeatAll>(S, st, o, d, kDblMax, hit, filter, cnt, gated, &is);
+                if (!any) break;
+                if (resolve_hit<false, kFeatAll, true>(S, o, d, hit, is, node_id) || gated) break;
+                gated = true;
+            }
+            if (any) {
+                r.toi = hit.t; r.normal[0] = is.n.x; r.normal[1] = is.n.y; r.normal[2] = is.n.z; r.uv[0] = is.u; r.uv[1] = is.v;
+                r.node_id = (int32_t)node_id; r.flags = 1u | (is.has_uv ? 2u : 0u);
+            }
+        }
+        out[i] = r;
+    }
 }
 
 // Wave tiles in descending order of last frame's cost.  XCD x's work list is the subset { i : i mod 8 == x } of the
@@ -588,12 +652,14 @@ struct NraysScene {
     DeviceCounters* d_counters = nullptr; // set used by the last frame
     uint64_t launch_index = 0, frame_index = 0;
     uint32_t* d_spill = nullptr;
+    long long* d_fixed = nullptr; size_t fixed_slots = 0; // per-pixel fixed-point sums of the queued chains (double-branching scenes)
     double* d_tables = nullptr; size_t tables_doubles = 0; // raygen tables: 4 * (width + height) f64
     uint32_t tab_w = 0, tab_h = 0; double tab_m[16] = {0}; bool tab_valid = false;
     // previous frame's wave-tile costs (k_primary) and the order derived from them (k_tile_order); valid for one
     // (width, rows, band) geometry at a time
     uint32_t* d_tile_cost = nullptr; uint32_t* d_tile_order = nullptr; uint32_t tile_slots = 0;
     uint64_t cost_key = 0; bool cost_valid = false;
+    uint32_t cost_tiles = 0, cost_grid = 0; // wave tiles / workgroups of the frame that recorded d_tile_cost last (nrays_get_tile_costs)
     // analytic scenes (workgroup lists): costs are recorded on the first frame of a camera, sorted once on the second, and
     // the order is then reused as long as the camera stays (the scene of a handle never changes)
     uint64_t cost_cam = 0, order_key = 0, order_cam = 0; bool order_valid = false; uint32_t order_age = 0;
@@ -621,6 +687,7 @@ struct NraysScene {
     DeviceCounters* d_counters_primary = nullptr; // snapshot taken right after the primary kernel
     hipStream_t last_stream = nullptr;
     hipEvent_t last_done = nullptr; // last event recorded by the previous render (one of the ring's events)
+    hipEvent_t ev_switch = nullptr; // recorded on the previous render's stream when a render arrives on another one
     bool have_last = false;
     // A/B and test switches, read ONCE when the handle is created (never in the frame path)
     uint64_t max_primary_per_launch = 32ull << 20; // NRAYS_MAX_PRIMARY: sample batching threshold (tests force several launches)
@@ -766,6 +833,13 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
         uint64_t want = std::min<uint64_t>(std::max<uint64_t>(4 * npix_local * batch, 1u << 16), 1ull << 27);
         int rc = ensure_queue(sc, (uint32_t)want);
         if (rc != NRAYS_OK) return rc;
+        const size_t slots = (size_t)npix_local * 3;
+        if (slots > sc->fixed_slots) {
+            if (sc->d_fixed) { (void)hipFree(sc->d_fixed); sc->d_fixed = nullptr; sc->fixed_slots = 0; }
+            HIP_TRY(hipMalloc((void**)&sc->d_fixed, slots * sizeof(long long)));
+            HIP_TRY(hipMemsetAsync(sc->d_fixed, 0, slots * sizeof(long long), stream)); // k_fold_fixed leaves it cleared
+            sc->fixed_slots = slots;
+        }
     }
     if (sc->spill_entries && !sc->d_spill) {
         HIP_TRY(hipMalloc((void**)&sc->d_spill, (size_t)kMaxGrid * kBlock * sc->spill_entries * sizeof(uint32_t)));
@@ -821,7 +895,11 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
     // handle execute one after the other: a render on a different stream than its predecessor is ordered behind it.
     if (sc->have_last && sc->last_stream != stream) {
         if (sc->last_timed && sc->last_done) HIP_TRY(hipStreamWaitEvent(stream, sc->last_done, 0));
-        else HIP_TRY(hipStreamSynchronize(sc->last_stream)); // the previous frame recorded no event to wait on
+        else { // the previous frame recorded no event (event_stride): mark the end of ITS stream now and wait on that — no host stall
+            if (!sc->ev_switch) HIP_TRY(hipEventCreateWithFlags(&sc->ev_switch, hipEventDisableTiming));
+            HIP_TRY(hipEventRecord(sc->ev_switch, sc->last_stream));
+            HIP_TRY(hipStreamWaitEvent(stream, sc->ev_switch, 0));
+        }
     }
     const bool timed = instrumented || (sc->frames_total % sc->event_stride) == 0;
     sc->frames_total++;
@@ -962,6 +1040,7 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
     HIP_TRY(hipMemsetAsync(sc->d_wave_times, 0, (size_t)kMaxGrid * (kBlock / 64) * 4 * sizeof(uint32_t), stream));
     R.wave_times = sc->d_wave_times; sc->dbg_grid = grid_primary;
 #endif
+    if (R.tile_cost) { sc->cost_tiles = lane_log2 ? win_units : win_units * 4u; sc->cost_grid = grid_primary; }
     bool first_primary = true;
     for (uint32_t s0 = 0; s0 < p->ray_per_pixel; s0 += batch) {
         R.sample_begin = s0; R.sample_end = std::min<uint32_t>(p->ray_per_pixel, s0 + batch);
@@ -984,6 +1063,7 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
         // count: the host only looks (one small copy + a stream synchronisation) before every FOURTH round — to stop, and to size
         // that group's grids — instead of before every round; a group's later rounds may find an empty queue and return at once.
         uint32_t n_seen = 0;
+        bool folded = true;
         for (uint32_t r = 1; queued && r <= (uint32_t)kMaxGenerations; ++r) {
             if ((r - 1u) % 4u == 0u) {
                 HIP_TRY(hipMemcpyAsync(&n_seen, sc->d_counts + r, sizeof n_seen, hipMemcpyDeviceToHost, stream));
@@ -994,9 +1074,16 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
             uint32_t grid = std::max<uint32_t>(std::min<uint32_t>((launch_n + kBlock - 1) / kBlock, kMaxGrid), std::min<uint32_t>((uint32_t)sc->num_cus, kMaxGrid));
             QueueOut qn; qn.q = sc->queue[(r + 1) & 1].q; qn.capacity = sc->queue_capacity; qn.count = sc->d_counts + r + 1;
             qn.overflow = &sc->d_counters->overflow;
-            if (instrumented) hipLaunchKernelGGL(k_bounce<true>, dim3(grid), dim3(kBlock), 0, stream, sc->d, sc->queue[r & 1].q, sc->d_counts + r, sc->queue_capacity, qn, d_out, sc->d_counters, sc->d_spill, p->max_depth);
-            else hipLaunchKernelGGL(k_bounce<false>, dim3(grid), dim3(kBlock), 0, stream, sc->d, sc->queue[r & 1].q, sc->d_counts + r, sc->queue_capacity, qn, d_out, sc->d_counters, sc->d_spill, p->max_depth);
+            if (instrumented) hipLaunchKernelGGL(k_bounce<true>, dim3(grid), dim3(kBlock), 0, stream, sc->d, sc->queue[r & 1].q, sc->d_counts + r, sc->queue_capacity, qn, sc->d_fixed, sc->d_counters, sc->d_spill, p->max_depth);
+            else hipLaunchKernelGGL(k_bounce<false>, dim3(grid), dim3(kBlock), 0, stream, sc->d, sc->queue[r & 1].q, sc->d_counts + r, sc->queue_capacity, qn, sc->d_fixed, sc->d_counters, sc->d_spill, p->max_depth);
             HIP_TRY(hipGetLastError());
+            folded = false;
+        }
+        if (queued && !folded) { // the next batch's k_primary continues the running sums in d_out: fold this batch's queued chains in first
+            const size_t n = (size_t)npix_local * 3;
+            hipLaunchKernelGGL(k_fold_fixed, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_out, sc->d_fixed, n);
+            HIP_TRY(hipGetLastError());
+            folded = true;
         }
     }
     if (p->ray_per_pixel > 1) {
@@ -1166,6 +1253,7 @@ void nrays_scene_destroy(NraysScene* sc) {
         if (sc->d_counters_set[k]) (void)hipFree(sc->d_counters_set[k]);
     }
     if (sc->d_spill) (void)hipFree(sc->d_spill);
+    if (sc->d_fixed) (void)hipFree(sc->d_fixed);
     if (sc->d_frame) (void)hipFree(sc->d_frame);
     if (sc->d_tables) (void)hipFree(sc->d_tables);
     if (sc->d_tile_cost) (void)hipFree(sc->d_tile_cost);
@@ -1174,6 +1262,7 @@ void nrays_scene_destroy(NraysScene* sc) {
     if (sc->d_rgb8) (void)hipFree(sc->d_rgb8);
     if (sc->h_cost_stats) (void)hipHostFree(sc->h_cost_stats);
     if (sc->ev_stats) (void)hipEventDestroy(sc->ev_stats);
+    if (sc->ev_switch) (void)hipEventDestroy(sc->ev_switch);
     if (sc->d_counters_primary) (void)hipFree(sc->d_counters_primary);
     for (int k = 0; k < NraysScene::kRing; ++k) {
         if (sc->ev_begin[k]) (void)hipEventDestroy(sc->ev_begin[k]);
@@ -1196,7 +1285,7 @@ int nrays_render_device_instrumented(NraysScene* scene, const NraysRenderParams*
 static void fill_counters(NraysStats* out, const DeviceCounters& c) {
     out->rays_reflection = c.rays_reflection; out->rays_refraction = c.rays_refraction; out->rays_shadow = c.rays_shadow;
     out->node_tests = c.node_tests; out->tri_tests = c.tri_tests; out->prim_tests = c.prim_tests;
-    out->hit_records = c.hit_records; out->tex_samples = c.tex_samples;
+    out->hit_records = c.hit_records; out->tex_samples = c.tex_samples; out->rays_primary_traced = c.rays_primary_traced;
 }
 
 int nrays_get_stats(NraysScene* sc, NraysStats* out) {
@@ -1225,6 +1314,19 @@ int nrays_get_stats(NraysScene* sc, NraysStats* out) {
     if (n) { out->kernel_ms_primary = sum_p / (double)n; out->kernel_ms_total = sum_t / (double)n; }
     out->frames_timed = (uint32_t)n;
     if (c.overflow) return fail(NRAYS_ERR_QUEUE_OVERFLOW, "continuation-ray queue overflow: image is incomplete");
+    return NRAYS_OK;
+}
+
+int nrays_get_tile_costs(NraysScene* sc, NraysTileCosts* out) {
+    if (!sc || !out) return fail(NRAYS_ERR_BAD_ARG, "null argument");
+    std::memset(out, 0, sizeof *out);
+    if (!sc->have_last || !sc->d_tile_cost || !sc->cost_valid || sc->cost_tiles == 0) return fail(NRAYS_ERR_BAD_ARG, "no frame of this handle has recorded its tile costs");
+    HIP_TRY(hipSetDevice(sc->device));
+    HIP_TRY(hipStreamSynchronize(sc->last_stream));
+    std::vector<uint32_t> c(sc->cost_tiles);
+    HIP_TRY(hipMemcpy(c.data(), sc->d_tile_cost, c.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    for (uint32_t v : c) { out->sum_cycles += (uint64_t)v * 16u; out->max_cycles = std::max<uint64_t>(out->max_cycles, (uint64_t)v * 16u); }
+    out->tiles = c.size(); out->resident_waves = (uint64_t)sc->cost_grid * (kBlock / 64);
     return NRAYS_OK;
 }
 
@@ -1324,6 +1426,29 @@ int nrays_render_rgb8(NraysScene* sc, const NraysRenderParams* p, uint8_t* out_r
         HIP_TRY(hipMemcpy(&overflow, &sc->d_counters->overflow, sizeof overflow, hipMemcpyDeviceToHost));
         if (overflow) return fail(NRAYS_ERR_QUEUE_OVERFLOW, "continuation-ray queue overflow: image is incomplete");
     }
+    return NRAYS_OK;
+}
+
+int nrays_debug_cast_batch(NraysScene* sc, uint32_t mode, uint32_t n, const double* origins, const double* dirs, const double* max_toi, NraysCastResult* out) {
+    if (!sc || !origins || !dirs || !out || mode > 1u || (mode == 1u && !max_toi)) return fail(NRAYS_ERR_BAD_ARG, "bad cast-batch arguments");
+    if (n == 0) return NRAYS_OK;
+    HIP_TRY(hipSetDevice(sc->device));
+    if (sc->have_last) HIP_TRY(hipStreamSynchronize(sc->last_stream));
+    if (sc->spill_entries && !sc->d_spill) HIP_TRY(hipMalloc((void**)&sc->d_spill, (size_t)kMaxGrid * kBlock * sc->spill_entries * sizeof(uint32_t)));
+    double *d_o = nullptr, *d_d = nullptr, *d_t = nullptr; NraysCastResult* d_r = nullptr;
+    auto release = [&]() { if (d_o) (void)hipFree(d_o); if (d_d) (void)hipFree(d_d); if (d_t) (void)hipFree(d_t); if (d_r) (void)hipFree(d_r); };
+#define CAST_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { release(); return fail(e_ == hipErrorOutOfMemory ? NRAYS_ERR_OOM : NRAYS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
+    const size_t vb = (size_t)n * 3 * sizeof(double);
+    CAST_TRY(hipMalloc((void**)&d_o, vb)); CAST_TRY(hipMalloc((void**)&d_d, vb)); CAST_TRY(hipMalloc((void**)&d_r, (size_t)n * sizeof(NraysCastResult)));
+    CAST_TRY(hipMemcpy(d_o, origins, vb, hipMemcpyHostToDevice)); CAST_TRY(hipMemcpy(d_d, dirs, vb, hipMemcpyHostToDevice));
+    if (mode == 1u) { CAST_TRY(hipMalloc((void**)&d_t, (size_t)n * sizeof(double))); CAST_TRY(hipMemcpy(d_t, max_toi, (size_t)n * sizeof(double), hipMemcpyHostToDevice)); }
+    const uint32_t grid = std::min<uint32_t>((n + kBlock - 1) / kBlock, (uint32_t)kMaxGrid);
+    hipLaunchKernelGGL(k_cast_batch, dim3(grid), dim3(kBlock), 0, sc->own_stream, sc->d, mode, n, d_o, d_d, d_t, d_r, sc->d_spill);
+    CAST_TRY(hipGetLastError());
+    CAST_TRY(hipStreamSynchronize(sc->own_stream));
+    CAST_TRY(hipMemcpy(out, d_r, (size_t)n * sizeof(NraysCastResult), hipMemcpyDeviceToHost));
+#undef CAST_TRY
+    release();
     return NRAYS_OK;
 }
 

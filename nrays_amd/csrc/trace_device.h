@@ -104,6 +104,7 @@ struct Cnt {
     unsigned shadow, refl, refr;            // ray classes, always counted
     unsigned max_depth;                     // deepest trace depth reached by this lane
     unsigned max_chain_nodes;               // instrumented: most AABB tests in one pixel's chain
+    unsigned traced;                        // instrumented: primary rays that entered the trace loop
 #ifdef NR_PHASE_TIMING
     unsigned cyc_node, cyc_leaf, cyc_other, cyc_tri; // per-wave cycles (valid in lane 0); cyc_tri is part of cyc_leaf
     unsigned wv_node, ln_node, wv_tri, ln_tri;       // iterations of the node loop / triangle loop: per wave (counted by the leading active lane) and per lane

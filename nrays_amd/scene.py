@@ -403,6 +403,40 @@ def render(scene, resolution, ray_per_pixel, window_width, camera_eye, projectio
     return out
 
 
+def cast_rays(scene, origins, dirs):
+    """The closest-hit query of Scene::trace (src/scene.rs:164-166) on caller-supplied rays, by the HIP traversal and
+    intersectors alone (nrays_debug_cast_batch).  Returns (hit mask, (n, 8) array of toi, nx, ny, nz, has_uv, u, v, node) —
+    the layout of oracle.cast."""
+    o = np.ascontiguousarray(origins, dtype=np.float64).reshape(-1, 3)
+    d = np.ascontiguousarray(dirs, dtype=np.float64).reshape(-1, 3)
+    n = len(o)
+    res = (abi.NraysCastResult * max(n, 1))()
+    abi.check(abi.load_hip_lib().nrays_debug_cast_batch(scene.device_handle(), 0, n, o.ctypes.data_as(C.POINTER(C.c_double)),
+                                                        d.ctypes.data_as(C.POINTER(C.c_double)), None, res))
+    out = np.zeros((n, 8), dtype=np.float64)
+    hit = np.zeros(n, dtype=bool)
+    for i in range(n):
+        r = res[i]
+        hit[i] = bool(r.flags & 1)
+        out[i] = (r.toi, r.normal[0], r.normal[1], r.normal[2], 1.0 if r.flags & 2 else 0.0, r.uv[0], r.uv[1], r.node_id)
+    return hit, out
+
+
+def shadow_rays(scene, origins, dirs, max_toi):
+    """Scene::intersects_ray (src/scene.rs:147-161) on caller-supplied rays by the HIP shadow traversal: returns
+    (blocked mask, (n, 3) colour filters)."""
+    o = np.ascontiguousarray(origins, dtype=np.float64).reshape(-1, 3)
+    d = np.ascontiguousarray(dirs, dtype=np.float64).reshape(-1, 3)
+    t = np.ascontiguousarray(max_toi, dtype=np.float64).reshape(-1)
+    n = len(o)
+    res = (abi.NraysCastResult * max(n, 1))()
+    abi.check(abi.load_hip_lib().nrays_debug_cast_batch(scene.device_handle(), 1, n, o.ctypes.data_as(C.POINTER(C.c_double)),
+                                                        d.ctypes.data_as(C.POINTER(C.c_double)), t.ctypes.data_as(C.POINTER(C.c_double)), res))
+    blocked = np.array([bool(res[i].flags & 1) for i in range(n)])
+    filt = np.array([[res[i].normal[0], res[i].normal[1], res[i].normal[2]] for i in range(n)], dtype=np.float64).reshape(n, 3)
+    return blocked, filt
+
+
 def get_stats(scene):
     st = abi.NraysStats()
     abi.check(abi.load_hip_lib().nrays_get_stats(scene.device_handle(), C.byref(st)))

@@ -1148,6 +1148,7 @@ static int oracle_render_impl(const NraysSceneDesc* desc, const NraysRenderParam
             stats->node_tests += jobs[t].cnt.node_tests; stats->tri_tests += jobs[t].cnt.tri_tests;
             stats->prim_tests += jobs[t].cnt.prim_tests; stats->hit_records += jobs[t].cnt.hit_records;
             stats->tex_samples += jobs[t].cnt.tex_samples;
+            stats->rays_primary_traced += jobs[t].cnt.rays_primary; /* the reference queries the BVT for every primary ray */
         }
         stats->instrumented = 1;
     }

@@ -13,7 +13,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import oracle  # noqa: E402
-from tests import scenes_util as su  # noqa: E402
+from tools import scenes_util as su  # noqa: E402
 
 CASES = {
     # name: (scene builder, width, height, camera_params kwargs)

@@ -18,7 +18,7 @@ import pytest
 import nrays_amd as nr
 import oracle
 from nrays_amd import abi, tiling
-from tests import scenes_util as su, standins
+from tools import scenes_util as su, standins
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4

@@ -9,7 +9,7 @@ import pytest
 import nrays_amd as nr
 import oracle
 from nrays_amd import abi, math3d, scenefile
-from tests import scenes_util as su
+from tools import scenes_util as su
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -166,7 +166,7 @@ def test_sponza_standin_through_the_file_front_end(host, tmp_path):
     """OBJ + MTL + PNG written by tools/gen_assets.py and parsed by the C++ loader give the same frame as
     the scene built in Python (low detail for speed)."""
     import tools.gen_assets as ga
-    from tests import standins
+    from tools import standins
     old = ga.MEDIA
     ga.MEDIA = str(tmp_path / "media")
     try:
@@ -186,7 +186,7 @@ def test_sponza_standin_through_the_file_front_end(host, tmp_path):
 
 
 def _python_sponza(detail):
-    from tests import standins
+    from tools import standins
     return standins.sponza_scene(detail)[0]
 
 

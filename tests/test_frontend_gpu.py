@@ -124,7 +124,7 @@ def test_render_rgb8_is_the_host_quantisation_of_the_float_frame(gpu):
     import numpy as np
     import nrays_amd as nr
     from nrays_amd import abi, tiling
-    from tests import scenes_util as su
+    from tools import scenes_util as su
     lib = abi.load_hip_lib()
     for make in (su.balls_scene, lambda: su.mesh_scene()):
         sc, cam = make()

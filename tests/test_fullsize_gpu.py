@@ -17,7 +17,7 @@ import pytest
 import nrays_amd as nr
 import oracle
 from nrays_amd import abi, scenefile
-from tests import scenes_util as su, standins
+from tools import scenes_util as su, standins
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -27,7 +27,7 @@ def test_hip_matches_golden(gpu, name):
     from nrays_amd import abi
     g = np.load(os.path.join(GOLD, name + ".npz"))
     build, w, h, kw = CASES[name]
-    from tests import scenes_util as su
+    from tools import scenes_util as su
     sc, cam = build()
     p, _ = su.camera_params(cam, w, h, **dict(kw))
     out = torch.empty((h, w, 3), dtype=torch.float32, device="cuda")

@@ -17,7 +17,7 @@ import pytest
 
 import nrays_amd as nr
 import oracle
-from tests import scenes_util as su
+from tools import scenes_util as su
 
 BALL, CUBOID, CYLINDER, CAPSULE, CONE = 0, 1, 2, 3, 4
 NAMES = {BALL: "ball", CUBOID: "cuboid", CYLINDER: "cylinder", CAPSULE: "capsule", CONE: "cone"}
@@ -53,8 +53,12 @@ def geometry(kind, prm):
             CAPSULE: lambda: nr.Capsule(prm[0], prm[1]), CONE: lambda: nr.Cone(prm[0], prm[1])}[kind]()
 
 
-@pytest.mark.parametrize("kind", [BALL, CUBOID, CYLINDER, CAPSULE, CONE])
-def test_shape_casts_against_independent_fixtures(kind):
+def oracle_cast(scene, o, d):
+    return oracle.cast(scene.descriptor, [o], [d])
+
+
+def check_shape_cases(kind, cast, label="oracle"):
+    """`cast(scene, o, d)` -> (hit mask, (1, 8) record): the oracle here, the HIP intersectors in test_kat_independent_gpu.py."""
     cases = np.load(FIXTURE)["cases"]
     cases = cases[cases[:, 0] == kind]
     assert len(cases) == 120
@@ -64,7 +68,7 @@ def test_shape_casts_against_independent_fixtures(kind):
         prm, t, w, solid = c[1:4], c[4:7], c[7:10], bool(c[10])
         o, d, hit, toi, was_inside = c[11:14], c[14:17], bool(c[17]), c[18], bool(c[19])
         node = nr.SceneNode(su.default_material(), 0.0, 0.0, 1.0, 1.0, nr.Isometry3(tuple(t), tuple(w)), geometry(kind, prm), None, solid)
-        got_hit, out = oracle.cast(nr.Scene([node], []).descriptor, [o], [d])
+        got_hit, out = cast(nr.Scene([node], []), o, d)
         assert bool(got_hit[0]) == hit, (NAMES[kind], c)
         if not hit:
             continue
@@ -92,13 +96,22 @@ def test_shape_casts_against_independent_fixtures(kind):
             worst["bound_rel"] = max(worst["bound_rel"], abs(bound - toi) / max(1.0, toi))
             if kind in (CYLINDER, CONE) and abs(abs(x[1]) - prm[0]) < 1e-9 * size:
                 n_rim += 1
-    print("%s: %d hits, max |toi - exact| / max(1, toi) = %.2e, supporting-plane residual / size = %.2e, "
-          "support-plane bound vs toi = %.2e, | |n| - 1 | = %.2e" % (NAMES[kind], n_hit, worst["toi_rel"], worst["plane_residual"], worst["bound_rel"], worst["unit"]))
+    print("%s %s: %d hits, max |toi - exact| / max(1, toi) = %.2e, supporting-plane residual / size = %.2e, "
+          "support-plane bound vs toi = %.2e, | |n| - 1 | = %.2e" % (label, NAMES[kind], n_hit, worst["toi_rel"], worst["plane_residual"], worst["bound_rel"], worst["unit"]))
     assert n_hit >= 80
     assert worst["toi_rel"] <= 1e-11 and worst["plane_residual"] <= 1e-9 and worst["bound_rel"] <= 1e-9 and worst["unit"] <= 1e-12
 
 
+@pytest.mark.parametrize("kind", [BALL, CUBOID, CYLINDER, CAPSULE, CONE])
+def test_shape_casts_against_independent_fixtures(kind):
+    check_shape_cases(kind, oracle_cast)
+
+
 def test_triangle_casts_against_independent_fixtures():
+    check_triangle_cases(oracle_cast)
+
+
+def check_triangle_cases(cast, label="oracle"):
     """ncollide triangle_ray_intersection + TriMesh uv interpolation (SURVEY B-8 / B-9, reference call site
     examples/loader3d.rs:695) against exact plane / barycentric solutions: toi, the flat normal facing the ray origin,
     the interpolated uv."""
@@ -111,7 +124,7 @@ def test_triangle_casts_against_independent_fixtures():
         hit, toi, n, u, v = bool(c[27]), c[28], c[29:32], c[32], c[33]
         mesh = nr.TriMesh(np.stack([A, B, C_]), np.array([[0, 1, 2]], dtype=np.uint32), uv)
         node = nr.SceneNode(su.default_material(), 0.0, 0.0, 1.0, 1.0, nr.Isometry3(tuple(t), tuple(w)), mesh)
-        got_hit, out = oracle.cast(nr.Scene([node], []).descriptor, [o], [d])
+        got_hit, out = cast(nr.Scene([node], []), o, d)
         assert bool(got_hit[0]) == hit
         if not hit:
             continue
@@ -120,6 +133,6 @@ def test_triangle_casts_against_independent_fixtures():
         worst["normal"] = max(worst["normal"], float(np.abs(out[0, 1:4] - n).max()))
         assert out[0, 4] == 1
         worst["uv"] = max(worst["uv"], abs(out[0, 5] - u), abs(out[0, 6] - v))
-    print("triangle: %d hits of %d, max |toi - exact| / max(1, toi) = %.2e, |n - exact| = %.2e, |uv - exact| = %.2e"
+    print(label + " triangle: %d hits of %d, max |toi - exact| / max(1, toi) = %.2e, |n - exact| = %.2e, |uv - exact| = %.2e"
           % (hits, len(tris), worst["toi_rel"], worst["normal"], worst["uv"]))
     assert hits >= 50 and worst["toi_rel"] <= 1e-11 and worst["normal"] <= 1e-10 and worst["uv"] <= 1e-10

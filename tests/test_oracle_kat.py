@@ -12,7 +12,7 @@ import pytest
 
 import nrays_amd as nr
 import oracle
-from tests import scenes_util as su
+from tools import scenes_util as su
 
 ISO = nr.Isometry3
 

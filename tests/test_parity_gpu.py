@@ -9,7 +9,7 @@ import pytest
 import nrays_amd as nr
 import oracle
 from nrays_amd import abi
-from tests import scenes_util as su
+from tools import scenes_util as su
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -174,14 +174,14 @@ def test_sponza_standin_including_the_symmetry_plane_ties(gpu):
     the centre pixel column (d.z == 0) hits ~160 triangles at the same toi.  Reference semantics =
     lexicographic min (toi, node, triangle) over hits whose node AABB and triangle AABB pass the exact
     ncollide slab test; the GPU culls conservatively in f32 and gates accepted hits with those tests."""
-    from tests import standins
+    from tools import standins
     sc, cam = standins.sponza_scene()
     compare(sc, cam, 160, 90, threads=32)
     compare(sc, cam, 96, 54, threads=32, max_depth=2)
 
 
 def test_hairball_standin_small(gpu):
-    from tests import standins
+    from tools import standins
     sc, cam = standins.hairball_scene(strands=400)
     compare(sc, cam, 128, 128, threads=32)
 
@@ -198,8 +198,14 @@ def test_double_branching_uses_the_compacted_queue(gpu):
              nr.SceneNode(nr.NormalMaterial(), 0.0, 0.0, 1.0, 1.0, iso((0, 0.3, 3.0)), nr.Ball(0.8))]
     sc = nr.Scene(nodes, [nr.Light((2.0, 6.0, -4.0), 0.0, 1, (1, 1, 1))])
     cam = dict(eye=(0.0, 2.0, -7.0), at=(0.0, 0.0, 0.0), fovy=45.0)
-    _, _, st, _ = compare(sc, cam, 160, 120)
+    img, _, st, _ = compare(sc, cam, 160, 120)
     assert st.rays_reflection > 0 and st.rays_refraction > 0 and st.generations >= 3
+    # the queued chains of a pixel are summed in fixed point (k_bounce / k_fold_fixed): the frame does not depend on the
+    # order in which they finish
+    p, _ = su.camera_params(cam, 160, 120)
+    for _ in range(3):
+        again, _ = hip_render(sc, p)
+        assert np.array_equal(again, img)
 
 
 def test_sample_batching_multiple_primary_launches(gpu, monkeypatch):
@@ -214,7 +220,7 @@ def test_sample_batching_multiple_primary_launches(gpu, monkeypatch):
 
 
 def test_area_lights_on_meshes_and_eight_lights(gpu):
-    from tests import standins
+    from tools import standins
     sc, cam = standins.sponza_scene(detail=0.1, n_lights=8)
     compare(sc, cam, 96, 54, threads=32)
     sc, cam = su.mesh_scene(n_lights=2)

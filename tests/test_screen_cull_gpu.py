@@ -13,7 +13,7 @@ import pytest
 import nrays_amd as nr
 import oracle
 from nrays_amd import abi
-from tests import scenes_util as su
+from tools import scenes_util as su
 
 pytestmark = pytest.mark.gpu
 CLASSES = ("rays_primary", "rays_reflection", "rays_refraction", "rays_shadow")

@@ -33,7 +33,7 @@ def _worker(rank, world, port, w, h, band, result_path):
     import torch
     import torch.distributed as dist
     import oracle
-    from tests import scenes_util as su
+    from tools import scenes_util as su
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)

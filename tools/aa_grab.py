@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.ins
 import torch
 import nrays_amd as nr
 from nrays_amd import abi
-from tests import scenes_util as su, standins
+from tools import scenes_util as su, standins
 lib = abi.load_hip_lib()
 w, h, spp = (int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (3840, 2160, 64)
 scene = sys.argv[4] if len(sys.argv) > 4 else "hairball"

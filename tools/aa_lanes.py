@@ -3,7 +3,7 @@ sys.path.insert(0, os.getcwd())
 import torch
 import nrays_amd as nr
 from nrays_amd import abi
-from tests import scenes_util as su, standins
+from tools import scenes_util as su, standins
 lib = abi.load_hip_lib()
 hs, hc = standins.hairball_scene()
 hd = hs.device_handle()

@@ -12,7 +12,7 @@ import torch
 import nrays_amd as nr
 import oracle
 from nrays_amd import abi
-from tests import scenes_util as su
+from tools import scenes_util as su
 
 lib = abi.load_hip_lib()
 

@@ -53,7 +53,7 @@ def save_png(path, rgba_bottom_first, kind):
 
 
 def gen_globe():
-    from tests import scenes_util as su
+    from tools import scenes_util as su
     p = os.path.join(MEDIA, "globe.png")
     if os.path.exists(p):
         return p
@@ -63,7 +63,7 @@ def gen_globe():
 
 
 def gen_sponza(detail):
-    from tests import standins
+    from tools import standins
     d = os.path.join(MEDIA, "crytek-sponza")
     obj = os.path.join(d, "sponza.obj")
     if os.path.exists(obj):
@@ -85,7 +85,7 @@ def gen_sponza(detail):
 
 
 def gen_hairball(strands):
-    from tests import standins
+    from tools import standins
     d = os.path.join(MEDIA, "hairball")
     obj = os.path.join(d, "hairball.obj")
     if os.path.exists(obj):

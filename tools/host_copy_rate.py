@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.ins
 import numpy as np
 import nrays_amd as nr
 from nrays_amd import abi
-from tests import scenes_util as su
+from tools import scenes_util as su
 lib = abi.load_hip_lib()
 sc, cam = su.balls_scene()
 p, _ = su.camera_params(cam, 1920, 1080)

@@ -21,7 +21,7 @@ def run_one(scene_name, steps, width, height, check):
     import torch
     import nrays_amd as nr
     from nrays_amd import abi
-    from tests import scenes_util as su, standins
+    from tools import scenes_util as su, standins
     torch.cuda.set_device(0)
     lib = abi.load_hip_lib()
     if scene_name == "balls":
@@ -37,7 +37,7 @@ def run_one(scene_name, steps, width, height, check):
         cam = dict(cam, eye=(0.0, 150.0, -300.0))
     elif scene_name == "sponza":
         sc, cam = standins.sponza_scene()
-    elif scene_name == "sponza8":
+    elif scene_name in ("sponza8", "config4"):
         sc, cam = standins.sponza_scene(n_lights=8)
     elif scene_name == "hairball":
         sc, cam = standins.hairball_scene()

@@ -18,7 +18,7 @@ def main():
     import torch
     import nrays_amd as nr
     from nrays_amd import abi
-    from tests import scenes_util as su, standins
+    from tools import scenes_util as su, standins
     lib = abi.load_hip_lib()
     for name in sys.argv[1:] or ["sponza", "hairball"]:
         sc, cam = {"sponza": standins.sponza_scene, "hairball": standins.hairball_scene,

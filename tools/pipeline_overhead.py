@@ -11,7 +11,7 @@ torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 import nrays_amd as nr
 from nrays_amd import abi, tiling
-from tests import scenes_util as su
+from tools import scenes_util as su
 lib = abi.load_hip_lib()
 sc, cam = su.balls_scene()
 W, H = 1920, 1080

@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.ins
 import torch
 import nrays_amd as nr
 from nrays_amd import abi
-from tests import scenes_util as su
+from tools import scenes_util as su
 lib = abi.load_hip_lib()
 def run(sc, cam, w, h, steps=50):
     p, _ = su.camera_params(cam, w, h)

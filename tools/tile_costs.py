@@ -9,7 +9,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 from nrays_amd import abi
-from tests import scenes_util as su, standins
+from tools import scenes_util as su, standins
 lib = abi.load_hip_lib()
 for name in sys.argv[1:] or ["sponza"]:
     sc, cam = {"sponza": standins.sponza_scene, "hairball": standins.hairball_scene, "sponza8": lambda: standins.sponza_scene(n_lights=8),

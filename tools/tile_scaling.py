@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.ins
 import torch
 import nrays_amd as nr
 from nrays_amd import abi, tiling
-from tests import scenes_util as su, standins
+from tools import scenes_util as su, standins
 
 lib = abi.load_hip_lib()
 

@@ -9,7 +9,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 from nrays_amd import abi
-from tests import scenes_util as su, standins
+from tools import scenes_util as su, standins
 lib = abi.load_hip_lib()
 name = sys.argv[1] if len(sys.argv) > 1 else "balls"
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 8
