@@ -268,6 +268,11 @@ typedef struct NraysCastResult {
 int nrays_debug_cast_batch(NraysScene* scene, uint32_t mode, uint32_t n, const double* origins, const double* dirs,
                            const double* max_toi, NraysCastResult* out);
 
+/* World AABB of scene node `node` as the device holds it: geometry.bounding_volume(&transform) of src/scene_node.rs:41 in the
+ * reference's arithmetic; the kernels apply ncollide's exact ray / AABB test to it for every accepted hit (the reference only casts
+ * a node whose AABB the ray passes, src/scene.rs:276).  out = {min x, y, z, max x, y, z}. */
+int nrays_debug_node_aabb(NraysScene* scene, uint32_t node, double out[6]);
+
 /* Device bytes of the flattened scene (BVH nodes, triangle records, instance / shading records, textures): what
  * a frame must read at least once — the compulsory part of bench.py's roofline block. */
 uint64_t nrays_scene_device_bytes(const NraysScene* scene);

@@ -1429,6 +1429,14 @@ int nrays_render_rgb8(NraysScene* sc, const NraysRenderParams* p, uint8_t* out_r
     return NRAYS_OK;
 }
 
+int nrays_debug_node_aabb(NraysScene* sc, uint32_t node, double out[6]) {
+    if (!sc || !out) return fail(NRAYS_ERR_BAD_ARG, "null argument");
+    if (!sc->d.node_aabbs || (size_t)node * 6 + 6 > sc->host.node_aabbs.size()) return fail(NRAYS_ERR_BAD_ARG, "node index out of range");
+    HIP_TRY(hipSetDevice(sc->device));
+    HIP_TRY(hipMemcpy(out, sc->d.node_aabbs + 6 * (size_t)node, 6 * sizeof(double), hipMemcpyDeviceToHost));
+    return NRAYS_OK;
+}
+
 int nrays_debug_cast_batch(NraysScene* sc, uint32_t mode, uint32_t n, const double* origins, const double* dirs, const double* max_toi, NraysCastResult* out) {
     if (!sc || !origins || !dirs || !out || mode > 1u || (mode == 1u && !max_toi)) return fail(NRAYS_ERR_BAD_ARG, "bad cast-batch arguments");
     if (n == 0) return NRAYS_OK;

@@ -23,6 +23,7 @@ struct Image8 { // what stb_image::load returns: `depth` interleaved u8 channels
     std::vector<uint8_t> data;
 };
 Image8 read_png(const std::string& path);
+Image8 read_image(const std::string& path); // stb_image's `load`: PNG, JPEG, BMP or TGA by content (src/texture2d.rs:95), image_codec.cpp
 void write_png_rgb8(const std::string& path, const uint8_t* rgb, uint32_t w, uint32_t h);
 std::vector<uint8_t> quantize_rgb8(const float* rgb, size_t n);
 void write_ppm(const std::string& path, const float* rgb, uint32_t w, uint32_t h);

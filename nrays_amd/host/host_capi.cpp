@@ -66,4 +66,14 @@ int nrays_host_read_png(const char* path, uint8_t* out, size_t capacity, uint32_
     } catch (const std::exception& e) { g_err = e.what(); return NRAYS_ERR_BAD_ARG; }
 }
 
+// The same for any format stb_image's load recognises by content (PNG, JPEG, BMP, TGA): src/texture2d.rs:95.
+int nrays_host_read_image(const char* path, uint8_t* out, size_t capacity, uint32_t* w, uint32_t* h) {
+    try {
+        Image8 im = read_image(path);
+        *w = im.width; *h = im.height;
+        if (out) { if (im.data.size() > capacity) { g_err = "buffer too small"; return NRAYS_ERR_BAD_ARG; } std::memcpy(out, im.data.data(), im.data.size()); }
+        return im.channels;
+    } catch (const std::exception& e) { g_err = e.what(); return NRAYS_ERR_BAD_ARG; }
+}
+
 } // extern "C"

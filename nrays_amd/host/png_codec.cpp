@@ -2,7 +2,8 @@
 //
 // Reader: what Texture2d::from_png needs from stb_image (src/texture2d.rs:78-177): 8-bit-per-channel
 // images of 1, 2, 3 or 4 channels, top row first.  Supports colour types 0/2/3/4/6, bit depths
-// 1-16 (16 keeps the high byte, <8 is expanded), non-interlaced, zlib stored/fixed/dynamic blocks.
+// 1-16 (16 keeps the high byte, <8 is expanded), Adam7 interlacing, zlib stored/fixed/dynamic blocks.
+// The other formats stb_image decodes (TGA, BMP, JPEG) and the format dispatch are in image_codec.cpp.
 // Writer: Image::to_png (src/image.rs:60-90) — RGB8 with `clamp(c*255, 0, 255)` truncated to u8 —
 // and Image::to_ppm (src/image.rs:27-58).
 #include "host.hpp"
@@ -151,7 +152,8 @@ Image8 read_png(const std::string& path) {
         else if (type == "IEND") break;
         p += 12 + len;
     }
-    if (!w || !h || interlace) throw std::runtime_error("png: unsupported (empty or interlaced): " + path);
+    if (!w || !h) throw std::runtime_error("png: empty image: " + path);
+    if (interlace > 1) throw std::runtime_error("png: bad interlace method: " + path);
     int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
     if (!ch) throw std::runtime_error("png: bad colour type");
     // legal (colour type, bit depth) pairs of the PNG specification; anything else would give a zero or garbage stride
@@ -160,28 +162,44 @@ Image8 read_png(const std::string& path) {
                                      : (depth == 8 || depth == 16);
     if (!depth_ok) throw std::runtime_error("png: bad bit depth for the colour type: " + path);
     if ((uint64_t)w * h > (1ull << 28)) throw std::runtime_error("png: image too large: " + path);
-    size_t bpp_bits = (size_t)ch * depth, stride = (w * bpp_bits + 7) / 8, bpp = std::max<size_t>(1, bpp_bits / 8);
+    const size_t bpp_bits = (size_t)ch * depth, bpp = std::max<size_t>(1, bpp_bits / 8);
     std::vector<uint8_t> raw = inflate_zlib(idat);
-    if (raw.size() < (stride + 1) * h) throw std::runtime_error("png: short image data");
-    std::vector<uint8_t> img(stride * h), zero(stride, 0);
-    for (uint32_t y = 0; y < h; ++y) {
-        const uint8_t* s = &raw[(stride + 1) * y]; int ft = s[0]; ++s;
-        uint8_t* o = &img[stride * y]; const uint8_t* up = y ? &img[stride * (y - 1)] : zero.data();
-        for (size_t x = 0; x < stride; ++x) {
-            int a = x >= bpp ? o[x - bpp] : 0, b = up[x], c = x >= bpp ? up[x - bpp] : 0, v = s[x];
-            switch (ft) { case 1: v += a; break; case 2: v += b; break; case 3: v += (a + b) / 2; break; case 4: v += paeth(a, b, c); break; default: break; }
-            o[x] = (uint8_t)v;
-        }
-    }
-    // unpack to 8 bits per sample
     std::vector<uint8_t> s8((size_t)w * h * ch);
-    for (uint32_t y = 0; y < h; ++y) for (uint32_t x = 0; x < w * (uint32_t)ch; ++x) {
-        const uint8_t* row = &img[stride * y]; uint8_t v;
-        if (depth == 8) v = row[x];
-        else if (depth == 16) v = row[2 * x];
-        else { int per = 8 / depth, sh = (per - 1 - (int)(x % per)) * depth; int raw_v = (row[x / per] >> sh) & ((1 << depth) - 1);
-               v = ctype == 3 ? (uint8_t)raw_v : (uint8_t)(raw_v * 255 / ((1 << depth) - 1)); }
-        s8[(size_t)y * w * ch + x] = v;
+    // One pass = a sub-image of pw x ph pixels whose pixel (i, j) is pixel (x0 + i dx, y0 + j dy) of the image: the whole image for
+    // a non-interlaced file, the seven Adam7 passes otherwise (stb_image decodes both).  Scanlines are unfiltered per pass.
+    size_t rpos = 0;
+    auto pass = [&](uint32_t x0, uint32_t y0, uint32_t dx, uint32_t dy) {
+        if (x0 >= w || y0 >= h) return;
+        const uint32_t pw = (w - x0 + dx - 1) / dx, ph = (h - y0 + dy - 1) / dy;
+        const size_t stride = (pw * bpp_bits + 7) / 8;
+        if (raw.size() < rpos + (stride + 1) * ph) throw std::runtime_error("png: short image data");
+        std::vector<uint8_t> img(stride * ph), zero(stride, 0);
+        for (uint32_t y = 0; y < ph; ++y) {
+            const uint8_t* s = &raw[rpos + (stride + 1) * y]; int ft = s[0]; ++s;
+            if (ft > 4) throw std::runtime_error("png: bad filter type");
+            uint8_t* o = &img[stride * y]; const uint8_t* up = y ? &img[stride * (y - 1)] : zero.data();
+            for (size_t x = 0; x < stride; ++x) {
+                int a = x >= bpp ? o[x - bpp] : 0, b = up[x], c = x >= bpp ? up[x - bpp] : 0, v = s[x];
+                switch (ft) { case 1: v += a; break; case 2: v += b; break; case 3: v += (a + b) / 2; break; case 4: v += paeth(a, b, c); break; default: break; }
+                o[x] = (uint8_t)v;
+            }
+        }
+        rpos += (stride + 1) * ph;
+        // unpack to 8 bits per sample
+        for (uint32_t y = 0; y < ph; ++y) for (uint32_t px = 0; px < pw; ++px) for (int cc = 0; cc < ch; ++cc) {
+            const uint32_t x = px * (uint32_t)ch + (uint32_t)cc;
+            const uint8_t* row = &img[stride * y]; uint8_t v;
+            if (depth == 8) v = row[x];
+            else if (depth == 16) v = row[2 * x];
+            else { int per = 8 / depth, sh = (per - 1 - (int)(x % per)) * depth; int raw_v = (row[x / per] >> sh) & ((1 << depth) - 1);
+                   v = ctype == 3 ? (uint8_t)raw_v : (uint8_t)(raw_v * 255 / ((1 << depth) - 1)); }
+            s8[((size_t)(y0 + y * dy) * w + (x0 + px * dx)) * ch + cc] = v;
+        }
+    };
+    if (!interlace) pass(0, 0, 1, 1);
+    else {
+        static const uint32_t a7[7][4] = {{0, 0, 8, 8}, {4, 0, 8, 8}, {0, 4, 4, 8}, {2, 0, 4, 4}, {0, 2, 2, 4}, {1, 0, 2, 2}, {0, 1, 1, 2}};
+        for (const auto& q : a7) pass(q[0], q[1], q[2], q[3]);
     }
     Image8 out; out.width = w; out.height = h;
     if (ctype == 3) { // palette -> RGB (RGBA if tRNS), like stb_image

@@ -280,7 +280,7 @@ struct Parser {
         auto it = tex_cache[opacity].find(path);
         if (it != tex_cache[opacity].end()) return it->second;
         std::shared_ptr<ImageData> data;
-        if (file_exists(path)) data = decode_texture(read_png(path), opacity);
+        if (file_exists(path)) data = decode_texture(read_image(path), opacity);
         else if (opt.allow_standins && path.size() >= 9 && path.compare(path.size() - 9, 9, "globe.png") == 0 && !opacity) {
             data = globe_standin(); sc.warnings.push_back("stand-in generated for missing " + path);
         } else throw std::runtime_error("Image not found: " + path);

@@ -46,6 +46,8 @@ def host_lib():
         l.nrays_host_write_ppm.argtypes = [C.c_char_p, C.POINTER(C.c_float), C.c_uint32, C.c_uint32]
         l.nrays_host_read_png.restype = C.c_int
         l.nrays_host_read_png.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        l.nrays_host_read_image.restype = C.c_int
+        l.nrays_host_read_image.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         _lib = l
     return _lib
 
@@ -125,4 +127,16 @@ def read_png(path):
         raise RuntimeError(host_lib().nrays_host_last_error().decode())
     buf = np.empty((h.value, w.value, ch), dtype=np.uint8)
     host_lib().nrays_host_read_png(os.fsencode(path), buf.ctypes.data, buf.nbytes, C.byref(w), C.byref(h))
+    return buf
+
+
+def read_image(path):
+    """What stb_image's load hands to Texture2d::from_png (src/texture2d.rs:95): PNG, JPEG, BMP or TGA, recognised by content;
+    (H, W, channels) uint8, top row first."""
+    w, h = C.c_uint32(), C.c_uint32()
+    ch = host_lib().nrays_host_read_image(os.fsencode(path), None, 0, C.byref(w), C.byref(h))
+    if ch < 0:
+        raise RuntimeError(host_lib().nrays_host_last_error().decode())
+    buf = np.empty((h.value, w.value, ch), dtype=np.uint8)
+    host_lib().nrays_host_read_image(os.fsencode(path), buf.ctypes.data, buf.nbytes, C.byref(w), C.byref(h))
     return buf

@@ -86,6 +86,33 @@ def test_sponza_scene_file_with_generated_assets_on_the_hip_path(gpu, tmp_path):
     assert st.rays_refraction > 0  # alpha-mapped foliage
 
 
+def test_sponza_textures_as_tga_give_the_same_frame_as_png(gpu, tmp_path):
+    """The Crytek Sponza distribution ships its textures as TGA; the reference decodes them through stb_image
+    (src/texture2d.rs:95).  The stand-in's textures written as TGA (run-length coded colour maps, raw 8-bit opacity maps,
+    bottom-up) must give the SAME texels and therefore the same frame, bit for bit, as the PNG files."""
+    import tools.gen_assets as ga
+    frames = {}
+    for ext in ("png", "tga"):
+        root = tmp_path / ext
+        root.mkdir()
+        old = ga.MEDIA
+        ga.MEDIA = str(root / "media")
+        try:
+            ga.gen_sponza(0.15, ext)
+        finally:
+            ga.MEDIA = old
+        assert any(f.endswith("." + ext) for f in os.listdir(str(root / "media" / "crytek-sponza" / "textures")))
+        text = open(os.path.join(ROOT, "scenes", "crytek_sponza.scene")).read()
+        fs = scenefile.FileScene(tf._scene(root, text))
+        assert fs.descriptor.desc.num_textures >= 8
+        cam = fs.camera_dict()
+        p = nr.make_params((160, 90), 1, 0.0, cam["eye"], fs.inverse_projection(0, 160, 90))
+        img = np.empty((90, 160, 3), np.float32)
+        abi.check(abi.load_hip_lib().nrays_render(fs.device_handle(), C.byref(p), img.ctypes.data_as(C.POINTER(C.c_float))))
+        frames[ext] = (img, nr.get_stats(fs).total_rays())
+    assert frames["png"][1] == frames["tga"][1] and np.array_equal(frames["png"][0], frames["tga"][0])
+
+
 def test_obj_quirks_on_the_hip_path(gpu, tmp_path):
     """src/obj.rs:232-273,334-366: the on-the-fly fan (v0,v1,v2),(v0,v2,v3),(v2,v3,v4), negative indices, a second
     `usemtl` splitting a group, `d 0.5` as node alpha — rendered, not just parsed."""

@@ -75,3 +75,28 @@ def test_hip_shadow_queries_equal_the_oracle(gpu):
             assert np.abs(filt[i] - f).max() <= 1e-6
             n_filtered += int((f != 1.0).any())
     assert 0 < blocked.sum() < len(o)
+
+
+# ---- second fixture set (tests/golden/make_kat_independent2.py): planes, shape AABBs, rotated meshes, coincident triangles
+def hip_aabb(scene, i):
+    import ctypes as C
+    from nrays_amd import abi
+    out = (C.c_double * 6)()
+    abi.check(abi.load_hip_lib().nrays_debug_node_aabb(scene.device_handle(), i, out))
+    return np.array(out[:])
+
+
+def test_hip_planes_against_independent_fixtures(gpu):
+    from tests import test_kat_independent2 as kat2
+    kat2.check_planes(hip_cast, "HIP")
+
+
+def test_device_aabbs_against_support_function_extremes(gpu):
+    from tests import test_kat_independent2 as kat2
+    kat2.check_aabbs(hip_aabb, "HIP")
+
+
+def test_hip_rotated_meshes_and_ties_against_independent_fixtures(gpu):
+    from tests import test_kat_independent2 as kat2
+    kat2.check_meshes(hip_cast, "HIP")
+    kat2.check_ties(hip_cast, "HIP")

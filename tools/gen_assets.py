@@ -44,12 +44,15 @@ def write_obj(path, pts, uvs, groups, mtllib=None):
 
 
 def save_png(path, rgba_bottom_first, kind):
+    """Writes the texture in the format of the path's extension (.png, .tga — run-length coded for colour maps, raw for opacity
+    maps — .bmp, .jpg): Texture2d::from_png decodes all of them through stb_image (texture2d.rs:95)."""
     from PIL import Image
     top_first = rgba_bottom_first[::-1]  # Texture2d::from_png flips Y on load (texture2d.rs:99-107)
+    kw = {"compression": "tga_rle"} if path.endswith(".tga") and kind != "alpha" else {}
     if kind == "alpha":
-        Image.fromarray(np.ascontiguousarray(top_first[..., 3])).save(path)  # depth 1 opacity map -> (1,1,1,g)
+        Image.fromarray(np.ascontiguousarray(top_first[..., 3])).save(path, **kw)  # depth 1 opacity map -> (1,1,1,g)
     else:
-        Image.fromarray(np.ascontiguousarray(top_first[..., :3])).save(path)  # depth 3 -> (r,g,b,1)
+        Image.fromarray(np.ascontiguousarray(top_first[..., :3])).save(path, **kw)  # depth 3 -> (r,g,b,1)
 
 
 def gen_globe():
@@ -62,7 +65,7 @@ def gen_globe():
     return p
 
 
-def gen_sponza(detail):
+def gen_sponza(detail, ext="png"):
     from tools import standins
     d = os.path.join(MEDIA, "crytek-sponza")
     obj = os.path.join(d, "sponza.obj")
@@ -71,14 +74,14 @@ def gen_sponza(detail):
     os.makedirs(os.path.join(d, "textures"), exist_ok=True)
     pts, uvs, groups, defs, tex = standins.sponza_geometry(detail)
     for name, t in tex.items():
-        save_png(os.path.join(d, "textures", name + ".png"), t.data.pixels, "alpha" if name in ("lace", "leaves") else "rgb")
+        save_png(os.path.join(d, "textures", name + "." + ext), t.data.pixels, "alpha" if name in ("lace", "leaves") else "rgb")
     with open(os.path.join(d, "sponza.mtl"), "w") as f:
         for name, (ka, kd, ks, t, a, ns, alpha) in defs.items():
             f.write("newmtl %s\nNs %.9g\nd %.9g\nKa %.9g %.9g %.9g\nKd %.9g %.9g %.9g\nKs %.9g %.9g %.9g\n" % ((name, ns, alpha) + tuple(ka) + tuple(kd) + tuple(ks)))
             if t:
-                f.write("map_Kd textures/%s.png\n" % t)
+                f.write("map_Kd textures/%s.%s\n" % (t, ext))
             if a:
-                f.write("map_d textures/%s.png\n" % a)
+                f.write("map_d textures/%s.%s\n" % (a, ext))
             f.write("\n")
     write_obj(obj, pts, uvs, groups, "sponza.mtl")
     return obj
