@@ -138,6 +138,7 @@ struct DeviceCounters {
     unsigned int max_depth; // deepest trace depth reached (= number of continuation generations)
     unsigned int max_chain_nodes; // instrumented: most AABB tests spent on one pixel's chain
     unsigned int pad;
+    unsigned long long dbg2[8];   // tuning builds (NR_PHASE_TIMING): wave cycles outside the queries — dequeue wait, raygen + root test, hit reconstruction + gates, shadow-ray set-up, material, weights + continuation, pixel write
     unsigned long long dbg[8];    // tuning builds (NR_PHASE_TIMING): wave / lane iteration counts of the node loops and triangle leaves, cycles per query class, wave-uniform node iterations
 };
 

@@ -82,6 +82,12 @@ __device__ __forceinline__ void flush_counters(DeviceCounters* ctr, const Cnt& c
     unsigned q0 = c.cyc_closest0, q1 = c.cyc_closestN, q2 = c.cyc_shadow, u0 = c.wv_uni;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { unsigned a = __shfl_down(q0, off), b = __shfl_down(q1, off), d = __shfl_down(q2, off); q0 = a > q0 ? a : q0; q1 = b > q1 ? b : q1; q2 = d > q2 ? d : q2; u0 += __shfl_down(u0, off); }
+    for (int k_ = 0; k_ < 8; ++k_) {
+        unsigned x_ = c.cyc_x[k_];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { unsigned a = __shfl_down(x_, off); x_ = a > x_ ? a : x_; }
+        if (__lane_id() == 0) atomicAdd(&ctr->dbg2[k_], (unsigned long long)x_);
+    }
     if (__lane_id() == 0) { atomicAdd(&ctr->dbg[4], (unsigned long long)q0); atomicAdd(&ctr->dbg[5], (unsigned long long)q1); atomicAdd(&ctr->dbg[6], (unsigned long long)q2); atomicAdd(&ctr->dbg[7], (unsigned long long)u0); }
     unsigned i0 = c.wv_node, i1 = c.ln_node, i2 = c.wv_tri, i3 = c.ln_tri;
 #pragma unroll
@@ -188,7 +194,7 @@ __global__ void __launch_bounds__(kBlock, waves_per_simd(FEAT)) k_primary(DScene
     st.init();
     Cnt cnt; cnt.node = cnt.tri = cnt.prim = cnt.hit = cnt.tex = cnt.shadow = cnt.refl = cnt.refr = cnt.max_depth = cnt.max_chain_nodes = cnt.traced = 0;
 #ifdef NR_PHASE_TIMING
-    cnt.cyc_node = cnt.cyc_leaf = cnt.cyc_other = cnt.cyc_tri = 0; cnt.wv_node = cnt.ln_node = cnt.wv_tri = cnt.ln_tri = 0; cnt.cyc_closest0 = cnt.cyc_closestN = cnt.cyc_shadow = 0; cnt.wv_uni = 0;
+    cnt.cyc_node = cnt.cyc_leaf = cnt.cyc_other = cnt.cyc_tri = 0; cnt.wv_node = cnt.ln_node = cnt.wv_tri = cnt.ln_tri = 0; cnt.cyc_closest0 = cnt.cyc_closestN = cnt.cyc_shadow = 0; cnt.wv_uni = 0; for (int k_ = 0; k_ < 8; ++k_) cnt.cyc_x[k_] = 0;
     unsigned long long twave = __builtin_readcyclecounter();
 #endif
 
@@ -234,6 +240,7 @@ __global__ void __launch_bounds__(kBlock, waves_per_simd(FEAT)) k_primary(DScene
     const bool prefetch = grab > 1u;
     uint32_t pending = grab ? issue_grab(work_counters, victim, grab) : 0u;
     for (;;) {
+      NR_TIC(tdq);
       uint32_t first, last;
       if (grab == 0u) {
           uint32_t k = 0;
@@ -283,6 +290,7 @@ __global__ void __launch_bounds__(kBlock, waves_per_simd(FEAT)) k_primary(DScene
           else { first = victim * per + k; last = k + grab < len ? first + grab : victim * per + len; }
           if (prefetch) pending = issue_grab(work_counters, victim, grab); // issued now, consumed after the tiles below
       }
+      NR_TOC(cyc_x[0], tdq);
       for (uint32_t wt = first; wt < last; ++wt) {
         const unsigned long long tile_t0 = R.tile_cost ? __builtin_readcyclecounter() : 0ULL;
 #ifdef NR_DEBUG_TILE_COSTS
@@ -325,12 +333,14 @@ __global__ void __launch_bounds__(kBlock, waves_per_simd(FEAT)) k_primary(DScene
             unsigned node_before = cnt.node;
             f3 c;
             bool wave_may_hit = false; // wave-uniform
+            NR_TIC(trg);
             if (!tile_misses) {
                 // lanes outside the frame (ragged right edge, padding rows of a band) still execute the ray generation: keep
                 // their table reads inside the tables
                 generate_primary<PLAIN>(R, i < R.width ? i : R.width - 1u, j < R.height ? j : R.height - 1u, s, pix, ray);
                 wave_may_hit = __ballot(sample_active && primary_may_hit(S, ray.o, ray.d)) != 0ULL;
             }
+            NR_TOC(cyc_x[1], trg);
             if (!wave_may_hit) {
                 // no ray of this wave tile gets past the root of the BVT: Scene::trace returns the background for
                 // all of them (scene.rs:157-161), without entering the trace loop
@@ -407,7 +417,7 @@ __global__ void __launch_bounds__(kBlock, NRAYS_WAVES_PER_SIMD) k_bounce(DScene 
     st.init();
     Cnt cnt; cnt.node = cnt.tri = cnt.prim = cnt.hit = cnt.tex = cnt.shadow = cnt.refl = cnt.refr = cnt.max_depth = cnt.max_chain_nodes = cnt.traced = 0;
 #ifdef NR_PHASE_TIMING
-    cnt.cyc_node = cnt.cyc_leaf = cnt.cyc_other = cnt.cyc_tri = 0; cnt.wv_node = cnt.ln_node = cnt.wv_tri = cnt.ln_tri = 0; cnt.cyc_closest0 = cnt.cyc_closestN = cnt.cyc_shadow = 0; cnt.wv_uni = 0;
+    cnt.cyc_node = cnt.cyc_leaf = cnt.cyc_other = cnt.cyc_tri = 0; cnt.wv_node = cnt.ln_node = cnt.wv_tri = cnt.ln_tri = 0; cnt.cyc_closest0 = cnt.cyc_closestN = cnt.cyc_shadow = 0; cnt.wv_uni = 0; for (int k_ = 0; k_ < 8; ++k_) cnt.cyc_x[k_] = 0;
 #endif
     uint32_t n = *count_in;
     if (n > capacity) n = capacity;
@@ -444,7 +454,7 @@ __global__ void __launch_bounds__(kBlock, NRAYS_WAVES_PER_SIMD) k_cast_batch(DSc
     st.init();
     Cnt cnt; cnt.node = cnt.tri = cnt.prim = cnt.hit = cnt.tex = cnt.shadow = cnt.refl = cnt.refr = cnt.max_depth = cnt.max_chain_nodes = cnt.traced = 0;
 #ifdef NR_PHASE_TIMING
-    cnt.cyc_node = cnt.cyc_leaf = cnt.cyc_other = cnt.cyc_tri = 0; cnt.wv_node = cnt.ln_node = cnt.wv_tri = cnt.ln_tri = 0; cnt.cyc_closest0 = cnt.cyc_closestN = cnt.cyc_shadow = 0; cnt.wv_uni = 0;
+    cnt.cyc_node = cnt.cyc_leaf = cnt.cyc_other = cnt.cyc_tri = 0; cnt.wv_node = cnt.ln_node = cnt.wv_tri = cnt.ln_tri = 0; cnt.cyc_closest0 = cnt.cyc_closestN = cnt.cyc_shadow = 0; cnt.wv_uni = 0; for (int k_ = 0; k_ < 8; ++k_) cnt.cyc_x[k_] = 0;
 #endif
     for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
         const uint32_t i = base + threadIdx.x;
@@ -1352,12 +1362,13 @@ int nrays_debug_wave_times(NraysScene* sc, uint32_t* out, uint32_t capacity_wave
 #endif
 #ifdef NR_PHASE_TIMING
 // Tuning builds only (tools/phase_timing.py): wave / lane iteration counts of the node loops and the triangle loops.
-int nrays_debug_counters(NraysScene* sc, unsigned long long out[8]) {
+int nrays_debug_counters(NraysScene* sc, unsigned long long out[16]) {
     if (!sc || !sc->have_last) return NRAYS_ERR_BAD_ARG;
     HIP_TRY(hipStreamSynchronize(sc->last_stream));
     DeviceCounters c;
     HIP_TRY(hipMemcpy(&c, sc->d_counters, sizeof c, hipMemcpyDeviceToHost));
     for (int k = 0; k < 8; ++k) out[k] = c.dbg[k];
+    for (int k = 0; k < 8; ++k) out[8 + k] = c.dbg2[k];
     return NRAYS_OK;
 }
 #endif

@@ -109,6 +109,7 @@ struct Cnt {
     unsigned cyc_node, cyc_leaf, cyc_other, cyc_tri; // per-wave cycles (valid in lane 0); cyc_tri is part of cyc_leaf
     unsigned wv_node, ln_node, wv_tri, ln_tri;       // iterations of the node loop / triangle loop: per wave (counted by the leading active lane) and per lane
     unsigned wv_uni;                                 // node-loop wave iterations in which every active lane fetches the SAME node
+    unsigned cyc_x[8];                               // wave cycles outside the queries (DeviceCounters::dbg2)
     unsigned cyc_closest0, cyc_closestN, cyc_shadow; // wave cycles inside the closest-hit query of primary rays / of continuation rays / inside shadow queries
 #endif
 };
@@ -515,7 +516,9 @@ NR_DEV f4 tex_sample(const ShadeTex& t, double u, double v, Cnt& cnt) {
         ux = ux < 0.0f ? 0.0f : (ux > 1.0f ? 1.0f : ux);
         uy = uy < 0.0f ? 0.0f : (uy > 1.0f ? 1.0f : uy);
     } else {
-        ux = fmodf(ux, 1.0f); uy = fmodf(uy, 1.0f);
+        // `% 1.0` (texture2d.rs:215-221) is fmodf(x, 1): the fractional part with the sign of x — x - trunc(x) is exact in f32, so
+        // three instructions give the library routine's value bit for bit (checked over 2 M values incl. -0, 2^23 and denormals)
+        ux = copysignf(ux - truncf(ux), ux); uy = copysignf(uy - truncf(uy), uy);
         if (ux < 0.0f) ux = 1.0f + ux;
         if (uy < 0.0f) uy = 1.0f + uy;
     }
@@ -1177,13 +1180,15 @@ NR_DEV f3 shade_hit(const DScene& S, Stack& st, RayState& ray, uint32_t depth, u
 #endif
         if (!any_hit)
             return F3(S.background[0] * ray.weight, S.background[1] * ray.weight, S.background[2] * ray.weight);
+        NR_TIC(trs);
         if (!(FEAT & kFeatMesh)) { // `is` is the winner's record already; only the deferred AABB gate is left
             const Instance& in = S.instances[hit.inst];
             node_id = (uint32_t)in.node_id;
             if (gated || in.kind == NRAYS_SHAPE_PLANE || node_aabb_pass(S, node_id, ray.o, ray.d)) break;
-        } else if (resolve_hit<false, FEAT, true>(S, ray.o, ray.d, hit, is, node_id) || gated) break;
+        } else { const bool ok_ = resolve_hit<false, FEAT, true>(S, ray.o, ray.d, hit, is, node_id); NR_TOC(cyc_x[2], trs); if (ok_ || gated) break; }
         gated = true;
     }
+    NR_TIC(tsh);
     // Single-sample lighting (one point light, or one area light with racsample 1): trace the shadow ray NOW,
     // while only the ray, the hit distance and the chain state are live, and hand the result to the Phong
     // evaluation below — the normal / uv / texture state then never has to survive a traversal.  Same ray,
@@ -1202,9 +1207,13 @@ NR_DEV f3 shade_hit(const DScene& S, Stack& st, RayState& ray, uint32_t depth, u
             ldir = ldir / nrm;
             cnt.shadow++;
             pre = true;
+            NR_TOC(cyc_x[3], tsh);
             NR_TIC(tsq);
             pre_lit = !shadow_query<STATS, FEAT>(S, st, point + ldir * 0.001, ldir, nrm - 0.001, pre_filter, cnt);
             NR_TOC(cyc_shadow, tsq);
+#ifdef NR_PHASE_TIMING
+            tsh = __builtin_readcyclecounter();
+#endif
         }
     }
     is.toi = hit.t;
@@ -1212,6 +1221,7 @@ NR_DEV f3 shade_hit(const DScene& S, Stack& st, RayState& ray, uint32_t depth, u
     const ShadeRec& sn = S.shade[node_id];
     d3 pt = ray.o + ray.d * hit.t;
     f4 obj = material_compute<STATS, FEAT>(S, st, sn, ray, pt, is, cnt, pre, pre_lit, pre_filter);
+    NR_TOC(cyc_x[4], tsh);
     bool may_recurse = depth < (uint32_t)kMaxGenerations && (max_depth == 0 || depth < max_depth);
     float mix = sn.refl_mix;
     float alpha = obj.w * sn.alpha;
@@ -1232,7 +1242,7 @@ NR_DEV f3 shade_hit(const DScene& S, Stack& st, RayState& ray, uint32_t depth, u
         rt.weight = ray.weight * (1.0f - alpha); rt.key = keyed ? rng_hash(ray.key, kSaltRefr) : 0ULL; rt.pixel = ray.pixel;
         cnt.refr++;
         if (do_refl) { if (FEAT & kFeatDouble) { extra = rt; has_extra = true; } }
-        else { ray = rt; has_next = true; return contrib; }
+        else { ray = rt; has_next = true; NR_TOC(cyc_x[5], tsh); return contrib; }
     }
     if (do_refl) { // scene.rs:204-214
         d3 rdir = ray.d - dirn * 2.0;
@@ -1240,6 +1250,7 @@ NR_DEV f3 shade_hit(const DScene& S, Stack& st, RayState& ray, uint32_t depth, u
         ray.weight = wa * mix; ray.key = keyed ? rng_hash(ray.key, kSaltRefl) : 0ULL;
         has_next = true; cnt.refl++;
     }
+    NR_TOC(cyc_x[5], tsh);
     return contrib;
 }
 

@@ -29,7 +29,7 @@ def main():
             abi.check(lib.nrays_render_device(sc.device_handle(), C.byref(p), C.c_void_p(out.data_ptr()), None))
         st = nr.get_stats(sc)
         tot = max(st.prim_tests, 1)
-        dbg = (C.c_ulonglong * 8)()
+        dbg = (C.c_ulonglong * 16)()
         lib.nrays_debug_counters.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
         abi.check(lib.nrays_debug_counters(sc.device_handle(), dbg))
         print(json.dumps({"scene": name, "ms": round(st.kernel_ms_primary, 3), "wave_cycles": st.prim_tests,
@@ -38,6 +38,8 @@ def main():
                           "outside_traversal": round(1 - (st.node_tests + st.tri_tests) / tot, 3),
                           "closest_queries_of_primary_rays": round(dbg[4] / tot, 3), "closest_queries_of_continuation_rays": round(dbg[5] / tot, 3),
                           "shadow_queries": round(dbg[6] / tot, 3),
+                          "outside_queries": {k: round(dbg[8 + i] / tot, 4) for i, k in enumerate(["dequeue_wait", "raygen_and_root_test", "hit_reconstruction_and_gates",
+                                                                                                      "shadow_ray_setup", "material", "weights_and_continuation"])},
                           "node_loop_wave_iterations_with_one_node_for_the_whole_wave": round(dbg[7] / max(dbg[0], 1), 3),
                           "node_loop": {"wave_iterations": dbg[0], "lane_iterations": dbg[1], "simd_efficiency": round(dbg[1] / max(64 * dbg[0], 1), 3),
                                         "cycles_per_wave_iteration": round(st.node_tests / max(dbg[0], 1))},
