@@ -478,7 +478,7 @@ def tiled_measure(name, W, H, steps, warmup, rank, world, owners):
 def run_tiled(args, rank, world, owners):
     W, H = args.width, args.height
     m = tiled_measure(args.scene, W, H, args.steps, args.warmup, rank, world, owners)
-    # the frame DESIGN.md 6 names as the one to tile (the metric's balls frame takes 0.05 ms on one GPU: the worst possible
+    # the frame DESIGN.md 7 names as the one to tile (the metric's balls frame takes 0.05 ms on one GPU: the worst possible
     # strong-scaling workload): BASELINE config 4, reported beside the contract's line at every N > 1
     sec = None
     if args.scene == "balls" and not args.no_secondary:
