@@ -187,3 +187,25 @@ def test_frames_enqueued_without_synchronisation(gpu):
         abi.check(lib.nrays_render_device(a.device_handle(), C.byref(p), C.c_void_p(out.data_ptr()), None))
     torch.cuda.synchronize()
     assert np.array_equal(out.cpu().numpy(), want)
+
+
+def test_one_handle_rendered_on_alternating_streams(gpu):
+    """A caller that double-buffers renders ONE handle on two streams in turn.  The handle owns per-frame device state, so the
+    library orders every render behind its predecessor — with an event recorded on the predecessor's stream when that frame
+    recorded none of its own (three frames out of four: the timing events are sampled), never with a host synchronisation.  Every
+    frame must equal the render of its camera on a fresh handle."""
+    import torch
+    lib = abi.load_hip_lib()
+    for make in (su.balls_scene, su.mesh_scene):
+        a, cam = make()
+        cams = [cam, dict(cam, eye=(cam["eye"][0] + 0.7, cam["eye"][1], cam["eye"][2])), dict(cam, fovy=cam["fovy"] * 1.2)]
+        params = [su.camera_params(c, 320, 180)[0] for c in cams]
+        want = [_render(make()[0], q)[0] for q in params]
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        outs = [torch.empty((180, 320, 3), dtype=torch.float32, device="cuda") for _ in range(12)]
+        for k, o in enumerate(outs):
+            s = streams[k & 1]
+            abi.check(lib.nrays_render_device(a.device_handle(), C.byref(params[k % 3]), C.c_void_p(o.data_ptr()), C.c_void_p(s.cuda_stream)))
+        torch.cuda.synchronize()
+        for k, o in enumerate(outs):
+            assert np.array_equal(o.cpu().numpy(), want[k % 3]), (make.__name__, k)
