@@ -229,6 +229,14 @@ struct DRender {
     uint32_t* wave_times; // tuning builds: per wave {kernel entry, first tile, exit} in 10 ns ticks (s_memrealtime) and its tile count
 #endif
     const uint32_t* tile_order;
+    // Light-parallel wave tiles (multi-light mesh frames): an entry of tile_order with bit 31 set stands for ONE of the 2^light_lsl
+    // parts of a wave tile (bits 28..30: which) — 64 >> light_lsl pixels, 2^light_lsl lanes per pixel, one light each in the
+    // shadow phase (material_compute) — so that the frame's few longest tiles (a closest-hit traversal + one shadow traversal PER
+    // LIGHT per layer, in sequence) are spread over 2^light_lsl waves and their lights run side by side.  order_len[x] = entries of
+    // XCD x's list (k_tile_order expands the tiles above its cost threshold).  Scheduling only: pixels do not depend on it.
+    const uint32_t* order_len;
+    uint32_t light_lsl;
 };
+constexpr uint32_t kEntrySplit = 0x80000000u, kEntryTileMask = 0x0fffffffu;
 
 } // namespace nrays

@@ -199,6 +199,7 @@ __global__ void __launch_bounds__(kBlock, waves_per_simd(FEAT)) k_primary(DScene
 #endif
 
     const uint32_t lane = threadIdx.x & 63u;
+    constexpr bool kLightSplit = !STATS && (FEAT & kFeatMultiSample) && (FEAT & kFeatMesh) && !(FEAT & kFeatDouble);
 #ifdef NR_DEBUG_TILE_COSTS
     const uint32_t dbg_t_entry = (uint32_t)__builtin_amdgcn_s_memrealtime();
     uint32_t dbg_t_first = 0u, dbg_tiles = 0u;
@@ -274,12 +275,16 @@ __global__ void __launch_bounds__(kBlock, waves_per_simd(FEAT)) k_primary(DScene
           // cheap tiles).
           const bool ordered = R.tile_order != nullptr;
           uint32_t k = (uint32_t)__builtin_amdgcn_readfirstlane((int)pending);
-          uint32_t len = ordered ? (nwt > victim ? (nwt - victim + 7u) / 8u : 0u) : (victim * per < nwt ? (nwt - victim * per < per ? nwt - victim * per : per) : 0u);
+          auto list_len = [&](uint32_t x) -> uint32_t {
+              if (ordered) return R.order_len ? R.order_len[x] : (nwt > x ? (nwt - x + 7u) / 8u : 0u);
+              return x * per < nwt ? (nwt - x * per < per ? nwt - x * per : per) : 0u;
+          };
+          uint32_t len = list_len(victim);
           if (k >= len) { // this XCD's list is exhausted: steal from the next non-empty one
               bool found = false;
               for (uint32_t tries = 0; tries < 7u && !found; ++tries) {
                   victim = (victim + 1u) & 7u;
-                  len = ordered ? (nwt > victim ? (nwt - victim + 7u) / 8u : 0u) : (victim * per < nwt ? (nwt - victim * per < per ? nwt - victim * per : per) : 0u);
+                  len = list_len(victim);
                   if (len == 0u) continue;
                   k = (uint32_t)__builtin_amdgcn_readfirstlane((int)issue_grab(work_counters, victim, grab));
                   if (k < len) found = true;
@@ -291,7 +296,10 @@ __global__ void __launch_bounds__(kBlock, waves_per_simd(FEAT)) k_primary(DScene
           if (prefetch) pending = issue_grab(work_counters, victim, grab); // issued now, consumed after the tiles below
       }
       NR_TOC(cyc_x[0], tdq);
-      for (uint32_t wt = first; wt < last; ++wt) {
+      for (uint32_t ent = first; ent < last; ++ent) {
+        // (an entry of a cost-ordered list may stand for one part of a light-parallel tile: DRender::light_lsl)
+        const uint32_t wt = kLightSplit ? (ent & kEntryTileMask) : ent;
+        const uint32_t lsl = (kLightSplit && (ent & kEntrySplit)) ? R.light_lsl : 0u, part = kLightSplit ? ((ent >> 28) & 7u) : 0u; // wave-uniform
         const unsigned long long tile_t0 = R.tile_cost ? __builtin_readcyclecounter() : 0ULL;
 #ifdef NR_DEBUG_TILE_COSTS
         if (dbg_tiles++ == 0u) dbg_t_first = (uint32_t)__builtin_amdgcn_s_memrealtime();
@@ -301,7 +309,8 @@ __global__ void __launch_bounds__(kBlock, waves_per_simd(FEAT)) k_primary(DScene
         if (lane_log2 == 0u) {
             uint32_t tile = wt >> 2, sub = wt & 3u;
             uint32_t tx = R.win_x0 + tile % R.win_nx, ty = R.win_y0 + tile / R.win_nx;
-            uint32_t lx = ((sub & 1u) << 3) | (lane & 7u), ly = ((sub >> 1) << 3) | (lane >> 3);
+            const uint32_t p = lane >> lsl;                               // pixel of this lane inside the entry's part of the tile
+            uint32_t lx = ((sub & 1u) << 3) | (p & 7u), ly = ((sub >> 1) << 3) | ((p >> 3) + part * (8u >> lsl));
             i = tx * kTile + lx; rl = ty * kTile + ly;
         } else {
             const uint32_t bwl = (7u - lane_log2) >> 1, bhl = (6u - lane_log2) >> 1; // the wave's pixel block is 2^bwl x 2^bhl
@@ -351,7 +360,7 @@ __global__ void __launch_bounds__(kBlock, waves_per_simd(FEAT)) k_primary(DScene
                 // instrumented renders only: a uniform counter in the tile loop of the plain kernels costs 25 us of the 52 us balls
                 // frame (profiles/r03 notes)
                 if (STATS && sample_active) cnt.traced++;
-                c = trace_chain<STATS, FEAT>(S, st, sample_active, ray, 0u, R.max_depth, qo, cnt, !PLAIN && R.use_rng != 0u);
+                c = trace_chain<STATS, FEAT>(S, st, sample_active, ray, 0u, R.max_depth, qo, cnt, !PLAIN && R.use_rng != 0u, lsl);
             }
             if (STATS) { unsigned dn = cnt.node - node_before; if (dn > cnt.max_chain_nodes) cnt.max_chain_nodes = dn; }
             if (lane_log2 == 0u) { tot.x = tot.x + c.x; tot.y = tot.y + c.y; tot.z = tot.z + c.z; }
@@ -363,16 +372,16 @@ __global__ void __launch_bounds__(kBlock, waves_per_simd(FEAT)) k_primary(DScene
                 }
             }
         }
-        if (active && q != 0u) { /* the group's first lane writes the pixel */ }
+        if (active && (q != 0u || (lane & ((1u << lsl) - 1u)) != 0u)) { /* the group's first lane writes the pixel */ }
         else if (active) {
             float* o = out + (size_t)pix * 3;
             o[0] = tot.x; o[1] = tot.y; o[2] = tot.z;
-        } else if (q == 0u && i < R.width && rl < R.rows_local && (PLAIN || R.first_batch)) { // padding rows of the last band
+        } else if (q == 0u && (lane & ((1u << lsl) - 1u)) == 0u && i < R.width && rl < R.rows_local && (PLAIN || R.first_batch)) { // padding rows of the last band
             float* o = out + (size_t)pix * 3;
             o[0] = 0.0f; o[1] = 0.0f; o[2] = 0.0f;
         }
-        if (R.tile_cost && lane == 0u) { // wave cycles spent on this tile, for the next frame's order
-            unsigned long long dt = (__builtin_readcyclecounter() - tile_t0) >> 4;
+        if (R.tile_cost && lane == 0u && part == 0u) { // wave cycles spent on this tile, for the next frame's order
+            unsigned long long dt = ((__builtin_readcyclecounter() - tile_t0) >> 4) << lsl; // (a light-parallel tile: its first part stands for all)
             R.tile_cost[wt] = dt > 0xffffffffULL ? 0xffffffffu : (uint32_t)dt;
         }
       }
@@ -492,28 +501,49 @@ __device__ __forceinline__ uint32_t cost_bucket(uint32_t c) {
     uint32_t m = e >= 3u ? (c >> (e - 3u)) & 7u : (c << (3u - e)) & 7u;
     return e * 8u + m;
 }
-__global__ void __launch_bounds__(1024) k_tile_order(const uint32_t* __restrict__ cost, uint32_t* __restrict__ order, uint32_t n, unsigned long long* stats) {
+// Light-parallel tiles (split_lsl > 0, multi-light mesh frames): a tile whose cost exceeds split_factor x the frame's work per
+// resident wave (its list's sum x 8 / waves: the lists are uniform samples of the image) would sit on the frame's critical path —
+// it enters the list as 2^split_lsl entries (its parts, DRender::light_lsl), each priced at a third of the tile.  split_factor < 0
+// splits every tile (tests).  order_len[x] receives the list's length.
+__global__ void __launch_bounds__(1024) k_tile_order(const uint32_t* __restrict__ cost, uint32_t* __restrict__ order, uint32_t n, unsigned long long* stats,
+                                                     uint32_t split_lsl, float split_factor, uint32_t waves, uint32_t* __restrict__ order_len) {
     __shared__ uint32_t hist[256];
     __shared__ unsigned long long wg_sum;
-    __shared__ uint32_t wg_max;
+    __shared__ uint32_t wg_max, wg_total;
     const uint32_t x = blockIdx.x; // 0..7
     if (threadIdx.x < 256u) hist[threadIdx.x] = 0u;
-    if (threadIdx.x == 0u) { wg_sum = 0ULL; wg_max = 0u; }
+    if (threadIdx.x == 0u) { wg_sum = 0ULL; wg_max = 0u; wg_total = 0u; }
     __syncthreads();
     unsigned long long my_sum = 0ULL; uint32_t my_max = 0u;
-    for (uint32_t i = x + 8u * threadIdx.x; i < n; i += 8u * 1024u) { const uint32_t c = cost[i]; atomicAdd(&hist[cost_bucket(c)], 1u); my_sum += c; my_max = c > my_max ? c : my_max; }
-    if (stats) { // stats[0] = sum of all tile costs, stats[1] = the largest one (both in the 16-cycle units of the cost array)
+    for (uint32_t i = x + 8u * threadIdx.x; i < n; i += 8u * 1024u) { const uint32_t c = cost[i]; my_sum += c; my_max = c > my_max ? c : my_max; }
+    if (stats || split_lsl) { // stats[0] = sum of all tile costs, stats[1] = the largest one (both in the 16-cycle units of the cost array)
         if (my_sum) atomicAdd(&wg_sum, my_sum);
         if (my_max) atomicMax(&wg_max, my_max);
     }
     __syncthreads();
     if (stats && threadIdx.x == 0u) { atomicAdd(&stats[0], wg_sum); atomicMax(&stats[1], (unsigned long long)wg_max); }
+    const unsigned long long thr = !split_lsl ? ~0ULL : (split_factor < 0.0f ? 0ULL : (unsigned long long)(split_factor * (double)(wg_sum * 8ULL) / (double)(waves ? waves : 1u)));
+    const uint32_t parts = 1u << split_lsl;
+    auto heavy = [&](uint32_t c) { return split_lsl != 0u && (unsigned long long)c >= thr && (split_factor < 0.0f || c != 0u); };
+    for (uint32_t i = x + 8u * threadIdx.x; i < n; i += 8u * 1024u) {
+        const uint32_t c = cost[i];
+        if (heavy(c)) atomicAdd(&hist[cost_bucket(c / 3u)], parts); else atomicAdd(&hist[cost_bucket(c)], 1u);
+    }
+    __syncthreads();
     if (threadIdx.x == 0) { // exclusive prefix, most expensive bucket first
         uint32_t acc = 0u;
         for (int b = 255; b >= 0; --b) { uint32_t c = hist[b]; hist[b] = acc; acc += c; }
+        wg_total = acc;
     }
     __syncthreads();
-    for (uint32_t i = x + 8u * threadIdx.x; i < n; i += 8u * 1024u) order[8u * atomicAdd(&hist[cost_bucket(cost[i])], 1u) + x] = i;
+    for (uint32_t i = x + 8u * threadIdx.x; i < n; i += 8u * 1024u) {
+        const uint32_t c = cost[i];
+        if (heavy(c)) {
+            const uint32_t at = atomicAdd(&hist[cost_bucket(c / 3u)], parts);
+            for (uint32_t s = 0; s < parts; ++s) order[8u * (at + s) + x] = i | (s << 28) | kEntrySplit;
+        } else order[8u * atomicAdd(&hist[cost_bucket(c)], 1u) + x] = i;
+    }
+    if (order_len && threadIdx.x == 0u) order_len[x] = wg_total;
 }
 
 // Screen bounds of the scene for one camera: the pixel rectangle outside of which no primary ray can reach the scene's
@@ -668,6 +698,9 @@ struct NraysScene {
     // previous frame's wave-tile costs (k_primary) and the order derived from them (k_tile_order); valid for one
     // (width, rows, band) geometry at a time
     uint32_t* d_tile_cost = nullptr; uint32_t* d_tile_order = nullptr; uint32_t tile_slots = 0;
+    // light-parallel tiles: log2 of the lanes per pixel (0 = the scene is not eligible), the split threshold in units of the frame's
+    // work per resident wave (NRAYS_LIGHT_SPLIT: 0 = never, < 0 = every tile, default 1), the lengths of the eight lists
+    uint32_t light_lsl = 0; float light_split_factor = 1.0f; uint32_t* d_order_len = nullptr;
     uint64_t cost_key = 0; bool cost_valid = false;
     uint32_t cost_tiles = 0, cost_grid = 0; // wave tiles / workgroups of the frame that recorded d_tile_cost last (nrays_get_tile_costs)
     // analytic scenes (workgroup lists): costs are recorded on the first frame of a camera, sorted once on the second, and
@@ -945,16 +978,21 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
     // 251 -> 222 ms without it, sponza 1080p 4 / 16 / 64 spp 2-4 %, profiles/r02_aa_lpt.log)
     bool lpt = grab >= 1u && lane_log2 == 0u;
     lpt = lpt && sc->lpt_enabled; // A/B switch (NRAYS_LPT=0)
+    if (instrumented && sc->light_lsl) lpt = false; // the instrumented kernel does not decode the split entries a plain frame's order may hold
     if (lpt) {
         const uint32_t nwt = std::max<uint32_t>(1u, lane_log2 ? win_units : win_units * 4u);
+        // light-parallel tiles (DRender::light_lsl): multi-light mesh scenes; the order array then holds up to 2^lsl entries per tile
+        const uint32_t split_lsl = (sc->light_lsl && sc->light_split_factor != 0.0f && !instrumented) ? sc->light_lsl : 0u;
         if (nwt > sc->tile_slots) {
             if (sc->d_tile_cost) { (void)hipFree(sc->d_tile_cost); sc->d_tile_cost = nullptr; }
             if (sc->d_tile_order) { (void)hipFree(sc->d_tile_order); sc->d_tile_order = nullptr; }
             sc->tile_slots = 0; sc->cost_valid = false; sc->order_valid = false;
             HIP_TRY(hipMalloc((void**)&sc->d_tile_cost, (size_t)nwt * sizeof(uint32_t)));
-            HIP_TRY(hipMalloc((void**)&sc->d_tile_order, (size_t)nwt * sizeof(uint32_t)));
+            HIP_TRY(hipMalloc((void**)&sc->d_tile_order, ((size_t)nwt << sc->light_lsl) * sizeof(uint32_t)));
             sc->tile_slots = nwt;
         }
+        if (split_lsl && !sc->d_order_len) HIP_TRY(hipMalloc((void**)&sc->d_order_len, 8 * sizeof(uint32_t)));
+        R.light_lsl = split_lsl; R.order_len = split_lsl ? sc->d_order_len : nullptr;
         const uint64_t key = (((uint64_t)p->width << 40) ^ ((uint64_t)rows << 20) ^ ((uint64_t)p->band_rows << 8) ^ ((uint64_t)p->band_owner << 4) ^ (uint64_t)R.band_owners ^ ((uint64_t)lane_log2 << 60))
                              + 0x9E3779B97F4A7C15ull * (((uint64_t)R.win_x0 << 48) ^ ((uint64_t)R.win_nx << 32) ^ ((uint64_t)R.win_y0 << 16) ^ (uint64_t)R.win_ny);
         // everything a tile's cost depends on besides the scene (which a handle never changes): a resting camera reuses its order
@@ -970,7 +1008,8 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
             if (sc->cost_valid && sc->cost_key == key) {
                 if (timed) HIP_TRY(hipEventRecord(sc->ev_begin[slot], stream));
                 sc->has_prepass[slot] = true;
-                hipLaunchKernelGGL(k_tile_order, dim3(8), dim3(1024), 0, stream, sc->d_tile_cost, sc->d_tile_order, nwt, (unsigned long long*)nullptr);
+                hipLaunchKernelGGL(k_tile_order, dim3(8), dim3(1024), 0, stream, sc->d_tile_cost, sc->d_tile_order, nwt, (unsigned long long*)nullptr,
+                                   split_lsl, sc->light_split_factor, grid_primary * (uint32_t)(kBlock / 64), split_lsl ? sc->d_order_len : (uint32_t*)nullptr);
                 HIP_TRY(hipGetLastError());
                 R.tile_order = sc->d_tile_order;
                 grab = 1u;
@@ -1019,7 +1058,7 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
             if (timed) HIP_TRY(hipEventRecord(sc->ev_begin[slot], stream));
             sc->has_prepass[slot] = true;
             HIP_TRY(hipMemsetAsync(sc->d_cost_stats, 0, 2 * sizeof(unsigned long long), stream));
-            hipLaunchKernelGGL(k_tile_order, dim3(8), dim3(1024), 0, stream, sc->d_tile_cost, sc->d_tile_order, nwt, sc->d_cost_stats);
+            hipLaunchKernelGGL(k_tile_order, dim3(8), dim3(1024), 0, stream, sc->d_tile_cost, sc->d_tile_order, nwt, sc->d_cost_stats, 0u, 0.0f, 0u, (uint32_t*)nullptr);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(sc->h_cost_stats, sc->d_cost_stats, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipEventRecord(sc->ev_stats, stream));
@@ -1223,6 +1262,9 @@ int nrays_scene_create(const NraysSceneDesc* desc, NraysScene** out_scene) {
     if (const char* e = getenv("NRAYS_GRAB")) sc->grab_override = std::max(0, atoi(e));
     if (const char* e = getenv("NRAYS_LPT")) sc->lpt_enabled = atoi(e) != 0;
     if (const char* e = getenv("NRAYS_SCREEN_CULL")) sc->cull_enabled = atoi(e) != 0;
+    { const int f = sc->features; // multi-light mesh scenes without double branching: 2, 4 or 8 lanes per pixel in a split tile
+      if ((f & kFeatMultiSample) && (f & kFeatMesh) && !(f & kFeatDouble) && h.lights.size() >= 2) { uint32_t l = 1; while (l < 3u && (2u << l) <= h.lights.size()) ++l; sc->light_lsl = l; } }
+    if (const char* e = getenv("NRAYS_LIGHT_SPLIT")) sc->light_split_factor = (float)atof(e);
     if (const char* e = getenv("NRAYS_LPT_ANALYTIC")) sc->lpt_analytic = atoi(e) != 0;
     if (const char* e = getenv("NRAYS_LPT_REUSE")) sc->lpt_reuse = atoi(e) != 0;
     if (const char* e = getenv("NRAYS_LEAD_WGS")) sc->lead_mode = atoi(e) != 0;
@@ -1268,6 +1310,7 @@ void nrays_scene_destroy(NraysScene* sc) {
     if (sc->d_tables) (void)hipFree(sc->d_tables);
     if (sc->d_tile_cost) (void)hipFree(sc->d_tile_cost);
     if (sc->d_tile_order) (void)hipFree(sc->d_tile_order);
+    if (sc->d_order_len) (void)hipFree(sc->d_order_len);
     if (sc->d_cost_stats) (void)hipFree(sc->d_cost_stats);
     if (sc->d_rgb8) (void)hipFree(sc->d_rgb8);
     if (sc->h_cost_stats) (void)hipHostFree(sc->h_cost_stats);

@@ -1055,9 +1055,13 @@ NR_DEV bool shadow_query(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, 
     return traverse<true, STATS, FEAT>(S, st, o, d, tlimit, dummy, filter, cnt);
 }
 #endif
+// `lsl` > 0 (light-parallel wave tiles, k_primary): 2^lsl consecutive lanes hold the SAME hit — they traced the same ray — and
+// share its light loop: lane slot j of the group traces the shadow rays of lights j, j + 2^lsl, ..., and the per-light sums are
+// then folded into `res` in light order by every lane of the group (`__shfl` from the lane that holds light l), i.e. exactly
+// `res = res + acc_l / n_l` light after light (phong_material.rs:106-147): the pixel is bit-identical to the one-lane loop.
 template <bool STATS, int FEAT>
 NR_MAT_ATTR f4 material_compute(const DScene& S, Stack& st, const ShadeRec& m, const RayState& ray, d3 point, const Isect& in, Cnt& cnt,
-                                bool pre, bool pre_lit, f3 pre_filter) {
+                                bool pre, bool pre_lit, f3 pre_filter, uint32_t lsl = 0u) {
     if (((m.flags >> 8) & 0xffu) != NRAYS_MAT_PHONG) return material_ambiant<STATS>(m, in, cnt);
     f4 tex; tex.x = tex.y = tex.z = tex.w = 1.0f;
     float alpha = 1.0f;
@@ -1065,8 +1069,8 @@ NR_MAT_ATTR f4 material_compute(const DScene& S, Stack& st, const ShadeRec& m, c
     if (in.has_uv && m.alpha_tex.texels) alpha = tex_sample<STATS>(m.alpha_tex, in.u, in.v, cnt).w;
     f3 res = F3(m.ka[0] * tex.x, m.ka[1] * tex.y, m.ka[2] * tex.z);
     d3 normal = in.n;
-#pragma nounroll
-    for (uint32_t li = 0; li < S.num_lights; ++li) {
+    // one light: the sum over its samples (light.rs:57-63 + phong_material.rs:108-146)
+    auto light_sum = [&](uint32_t li) -> f3 {
         const LightRec& light = S.lights[li];
         f3 acc = F3(0.0f, 0.0f, 0.0f);
         uint32_t ns = light.racsample * light.racsample;
@@ -1115,8 +1119,31 @@ NR_MAT_ATTR f4 material_compute(const DScene& S, Stack& st, const ShadeRec& m, c
                 acc.z = acc.z + light.color[2] * (filter.z * diffuse.z);
             }
         }
-        float inv = 1.0f / (float)(light.racsample * light.racsample);
-        res.x = inv * acc.x + res.x; res.y = inv * acc.y + res.y; res.z = inv * acc.z + res.z;
+        return acc;
+    };
+    constexpr bool kSplit = (FEAT & kFeatMultiSample) && (FEAT & kFeatMesh) && !(FEAT & kFeatDouble);
+    if (kSplit && lsl != 0u) { // wave-uniform
+        const uint32_t nslot = 1u << lsl, lane = __lane_id(), slot = lane & (nslot - 1u), gbase = lane & ~(nslot - 1u);
+#pragma nounroll
+        for (uint32_t base = 0; base < S.num_lights; base += nslot) {
+            const uint32_t li = base + slot;
+            f3 acc = F3(0.0f, 0.0f, 0.0f);
+            if (li < S.num_lights) acc = light_sum(li);
+            for (uint32_t j = 0; j < nslot && base + j < S.num_lights; ++j) { // wave-uniform bounds
+                const uint32_t rs = S.lights[base + j].racsample;
+                const float inv = 1.0f / (float)(rs * rs);
+                const float ax = __shfl(acc.x, (int)(gbase + j)), ay = __shfl(acc.y, (int)(gbase + j)), az = __shfl(acc.z, (int)(gbase + j));
+                res.x = inv * ax + res.x; res.y = inv * ay + res.y; res.z = inv * az + res.z;
+            }
+        }
+    } else {
+#pragma nounroll
+        for (uint32_t li = 0; li < S.num_lights; ++li) {
+            const f3 acc = light_sum(li);
+            const uint32_t rs = S.lights[li].racsample;
+            float inv = 1.0f / (float)(rs * rs);
+            res.x = inv * acc.x + res.x; res.y = inv * acc.y + res.y; res.z = inv * acc.z + res.z;
+        }
     }
     f4 out; out.x = res.x; out.y = res.y; out.z = res.z; out.w = alpha;
     return out;
@@ -1166,7 +1193,9 @@ NR_DEV void emit_rays(const QueueOut& qo, bool has, const RayState& r, uint32_t 
 // continuation (has_next); a second continuation (only possible in kFeatDouble scenes) goes to `extra`.
 template <bool STATS, int FEAT>
 NR_DEV f3 shade_hit(const DScene& S, Stack& st, RayState& ray, uint32_t depth, uint32_t max_depth,
-                    bool& has_next, bool& has_extra, RayState& extra, Cnt& cnt, bool keyed) {
+                    bool& has_next, bool& has_extra, RayState& extra, Cnt& cnt, bool keyed, uint32_t lsl = 0u) {
+    // light-parallel wave tiles: the 2^lsl lanes of a pixel trace the SAME chain; only the group's first lane counts its rays
+    const bool count_me = lsl == 0u || (__lane_id() & ((1u << lsl) - 1u)) == 0u;
     has_next = false; has_extra = false;
     Hit hit; f3 nofilter = F3(1.0f, 1.0f, 1.0f);
     Isect is; uint32_t node_id;
@@ -1220,7 +1249,7 @@ NR_DEV f3 shade_hit(const DScene& S, Stack& st, RayState& ray, uint32_t depth, u
     if (STATS) cnt.hit++;
     const ShadeRec& sn = S.shade[node_id];
     d3 pt = ray.o + ray.d * hit.t;
-    f4 obj = material_compute<STATS, FEAT>(S, st, sn, ray, pt, is, cnt, pre, pre_lit, pre_filter);
+    f4 obj = material_compute<STATS, FEAT>(S, st, sn, ray, pt, is, cnt, pre, pre_lit, pre_filter, lsl);
     NR_TOC(cyc_x[4], tsh);
     bool may_recurse = depth < (uint32_t)kMaxGenerations && (max_depth == 0 || depth < max_depth);
     float mix = sn.refl_mix;
@@ -1240,7 +1269,7 @@ NR_DEV f3 shade_hit(const DScene& S, Stack& st, RayState& ray, uint32_t depth, u
         RayState rt;
         rt.o = pt + new_dir * 0.001; rt.d = new_dir; rt.refr = n2; rt.energy = ray.energy;
         rt.weight = ray.weight * (1.0f - alpha); rt.key = keyed ? rng_hash(ray.key, kSaltRefr) : 0ULL; rt.pixel = ray.pixel;
-        cnt.refr++;
+        if (count_me) cnt.refr++;
         if (do_refl) { if (FEAT & kFeatDouble) { extra = rt; has_extra = true; } }
         else { ray = rt; has_next = true; NR_TOC(cyc_x[5], tsh); return contrib; }
     }
@@ -1248,7 +1277,7 @@ NR_DEV f3 shade_hit(const DScene& S, Stack& st, RayState& ray, uint32_t depth, u
         d3 rdir = ray.d - dirn * 2.0;
         ray.o = pt + rdir * 0.001; ray.d = rdir; ray.energy = ray.energy - sn.refl_atenuation;
         ray.weight = wa * mix; ray.key = keyed ? rng_hash(ray.key, kSaltRefl) : 0ULL;
-        has_next = true; cnt.refl++;
+        has_next = true; if (count_me) cnt.refl++;
     }
     NR_TOC(cyc_x[5], tsh);
     return contrib;
@@ -1262,14 +1291,14 @@ NR_DEV f3 shade_hit(const DScene& S, Stack& st, RayState& ray, uint32_t depth, u
 // `keyed`: the frame consumes RNG keys (AA jitter or an area light); otherwise the per-bounce key hashes are skipped.
 template <bool STATS, int FEAT>
 NR_DEV f3 trace_chain(const DScene& S, Stack& st, bool alive, RayState ray, uint32_t depth, uint32_t max_depth,
-                      const QueueOut& qo, Cnt& cnt, bool keyed) {
+                      const QueueOut& qo, Cnt& cnt, bool keyed, uint32_t lsl = 0u) {
     f3 sum = F3(0.0f, 0.0f, 0.0f);
     while (__ballot(alive) != 0ULL) { // wave-uniform
         bool has_extra = false;
         RayState extra;
         if (FEAT & kFeatDouble) extra = ray;
         if (alive) {
-            f3 c = shade_hit<STATS, FEAT>(S, st, ray, depth, max_depth, alive, has_extra, extra, cnt, keyed);
+            f3 c = shade_hit<STATS, FEAT>(S, st, ray, depth, max_depth, alive, has_extra, extra, cnt, keyed, lsl);
             sum.x = sum.x + c.x; sum.y = sum.y + c.y; sum.z = sum.z + c.z;
             if (depth > cnt.max_depth) cnt.max_depth = depth;
         }
