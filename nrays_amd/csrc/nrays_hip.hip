@@ -116,10 +116,11 @@ __device__ __forceinline__ void flush_counters(DeviceCounters* ctr, const Cnt& c
     }
 }
 
-// Waves per SIMD requested per permutation (measured on MI355X, tools/kbench.py): the opaque mesh
-// kernel is latency-bound and prefers 3 waves with a few spills; the others run best at 2 without.
+// Waves per SIMD requested per permutation (measured on MI355X, tools/kbench.py): the opaque mesh kernel is throughput-bound (hair:
+// 17 % SIMD efficiency in the node loops, no deep chains) and prefers 4 waves with 88 spilled dwords — hairball 2.82 -> 2.66 ms, config 5
+// 203.9 -> 194.0 ms against 3 waves; 5 / 6 waves: 3.59 / 5.21 ms (round 3); the others run best at 2 without spills.
 #ifndef NR_OPAQUE_MESH_WAVES
-#define NR_OPAQUE_MESH_WAVES 3
+#define NR_OPAQUE_MESH_WAVES 4
 #endif
 constexpr int waves_per_simd(int feat) { return (feat & ~(kFeatMultiSample | kFeatLdsScene)) == kFeatMesh ? (NRAYS_WAVES_PER_SIMD > NR_OPAQUE_MESH_WAVES ? NRAYS_WAVES_PER_SIMD : NR_OPAQUE_MESH_WAVES) : NRAYS_WAVES_PER_SIMD; }
 
