@@ -146,8 +146,11 @@ __device__ __noinline__ void fill_background_row(float bg0, float bg1, float bg2
     }
 }
 
-template <bool STATS, int FEAT, bool PLAIN = false>
-__global__ void __launch_bounds__(kBlock, waves_per_simd(FEAT)) k_primary(DScene S0, DRender R, QueueOut qo, float* __restrict__ out, DeviceCounters* ctr,
+// OCC != 0: the alpha-shadow mesh permutations also exist at three waves per SIMD (168 VGPRs, ~64 dwords of scratch per lane): a
+// wave then runs slower, which lengthens a frame that is as long as its longest tile (sponza 1080p: 1.40 -> 1.67 ms) and shortens a
+// frame that is bound by the sum of its tiles (sponza 4K: 4.12 -> 3.65 ms, config 4: 14.6 -> 12.5 ms) — render_impl chooses per frame.
+template <bool STATS, int FEAT, bool PLAIN = false, int OCC = 0>
+__global__ void __launch_bounds__(kBlock, OCC ? OCC : waves_per_simd(FEAT)) k_primary(DScene S0, DRender R, QueueOut qo, float* __restrict__ out, DeviceCounters* ctr,
                                                      uint32_t* spill, uint32_t tiles_x, uint32_t tiles_y, uint32_t* work_counters, uint32_t grab_arg,
                                                      uint32_t* zero_counts, DeviceCounters* zero_ctr) {
     // The scheduling path is fixed by the permutation — workgroup lists (0) for analytic-only scenes, XCD-aware HBM
@@ -751,6 +754,7 @@ struct NraysScene {
     double lone_factor = 1.5;                       // NRAYS_LONE_FACTOR: cost-ordered lead / second lists when sum / max of the tile costs < factor * SIMDs
     int lead_per_wg = 4;                            // NRAYS_LEAD_PER_WG=1..4: long entries per lead workgroup
     bool lead_mode = true;                          // NRAYS_LEAD_WGS=0: cost-ordered lists run on one workgroup per CU instead of lead + second workgroups
+    int occ_override = -1;                          // NRAYS_OCC=2|3: waves per SIMD of the alpha-shadow mesh kernels (A/B)
     bool cull_enabled = true;                       // NRAYS_SCREEN_CULL=0: no wave tile is decided from the scene's screen bounds
     NraysStats last;
     uint64_t last_primary = 0, last_primary_first_batch = 0;
@@ -804,7 +808,7 @@ static uint32_t tile_rows(const NraysRenderParams* p) {
 
 // The primary kernel is instantiated per feature set; instrumented renders and k_bounce use the
 // full-featured code (their results are identical, only slower).
-static void launch_primary(bool instrumented, int features, uint32_t grid, hipStream_t stream, const DScene& d, const DRender& R,
+static void launch_primary(bool instrumented, int features, int occ, uint32_t grid, hipStream_t stream, const DScene& d, const DRender& R,
                            const QueueOut& qo, float* out, DeviceCounters* ctr, uint32_t* spill, uint32_t tx, uint32_t ty, uint32_t* work, uint32_t grab,
                            uint32_t* zero_counts, DeviceCounters* zero_ctr) {
 #define NR_LAUNCH(F) hipLaunchKernelGGL((k_primary<false, F>), dim3(grid), dim3(kBlock), 0, stream, d, R, qo, out, ctr, spill, tx, ty, work, grab, zero_counts, zero_ctr)
@@ -812,6 +816,19 @@ static void launch_primary(bool instrumented, int features, uint32_t grid, hipSt
     // plain frames (tables, no RNG keys, one sample per pixel) of the analytic-only permutations
     const bool plain = R.col_tab && !R.use_rng && R.first_batch && R.sample_begin == 0u && R.sample_end == 1u;
 #define NR_LAUNCH_PLAIN(F) hipLaunchKernelGGL((k_primary<false, F, true>), dim3(grid), dim3(kBlock), 0, stream, d, R, qo, out, ctr, spill, tx, ty, work, grab, zero_counts, zero_ctr)
+    if (occ == 3) { // the three-wave builds of the alpha-shadow mesh permutations
+#define NR_LAUNCH_OCC3(F, P) hipLaunchKernelGGL((k_primary<false, F, P, 3>), dim3(grid), dim3(kBlock), 0, stream, d, R, qo, out, ctr, spill, tx, ty, work, grab, zero_counts, zero_ctr)
+        switch (features) {
+        case 6: if (plain) NR_LAUNCH_OCC3(6, true); else NR_LAUNCH_OCC3(6, false); return;
+        case 22: if (plain) NR_LAUNCH_OCC3(22, true); else NR_LAUNCH_OCC3(22, false); return;
+#ifndef NR_ONLY_MESH
+        case 7: NR_LAUNCH_OCC3(7, false); return;
+        case 23: NR_LAUNCH_OCC3(23, false); return;
+#endif
+        default: break;
+        }
+#undef NR_LAUNCH_OCC3
+    }
 #ifndef NR_ONLY_MESH // tuning builds: only the mesh permutations (everything else renders with the full kernel)
     if (plain && features == 33) { NR_LAUNCH_PLAIN(33); return; }
     if (plain && features == 37) { NR_LAUNCH_PLAIN(37); return; }
@@ -931,8 +948,17 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
     uint32_t grab = sc->host.any_mesh ? 1u : 0u; // 0 = workgroup lists through LDS; the specialised kernels fix their path at compile time
     if (sc->grab_override >= 0) grab = (uint32_t)sc->grab_override; // tiles per dequeue of the mesh kernels, A/B only (NRAYS_GRAB); pixels do not depend on it
     // persistent grid: exactly the workgroups that can be resident (one 4-wave workgroup per CU per wave/SIMD)
+    // Waves per SIMD of the alpha-shadow mesh permutations (k_primary's OCC): three for multi-light frames (their long tiles are split
+    // into light-parallel parts, so the frame is bound by its sum) and for frames with many tiles per resident wave, two otherwise
+    // (the frame is as long as its longest tile, and that tile's wave is fastest at two).  NRAYS_OCC overrides.
+    int occ = 0;
+    if (!instrumented && (sc->features == 6 || sc->features == 7 || sc->features == 22 || sc->features == 23) && lane_log2 == 0u) {
+        const uint64_t wave_tiles = (uint64_t)ntiles * 4u, waves2 = (uint64_t)sc->num_cus * 8u;
+        occ = ((sc->features & kFeatMultiSample) && sc->light_lsl && sc->light_split_factor != 0.0f) || wave_tiles >= 24u * waves2 ? 3 : 0;
+        if (sc->occ_override >= 0) occ = sc->occ_override == 3 ? 3 : 0;
+    }
     uint32_t grid_primary = std::min<uint32_t>(std::min<uint32_t>(((ntiles + 7u) / 8u) * 8u, (uint32_t)kMaxGrid),
-                                                     (uint32_t)sc->num_cus * (uint32_t)waves_per_simd(instrumented ? kFeatAll : sc->features) * 256u / (uint32_t)kBlock);
+                                                     (uint32_t)sc->num_cus * (uint32_t)(occ ? occ : waves_per_simd(instrumented ? kFeatAll : sc->features)) * 256u / (uint32_t)kBlock);
     if (sc->grid_wg_per_cu > 0) grid_primary = std::min<uint32_t>(grid_primary, (uint32_t)sc->num_cus * (uint32_t)sc->grid_wg_per_cu); // NRAYS_GRID_WG_PER_CU: occupancy sensitivity runs
 
     // All per-handle state (double-buffered counters, queues, raygen tables, tile costs) assumes that the renders of one
@@ -1101,7 +1127,7 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
         QueueOut qo; qo.q = sc->queue[1].q; qo.capacity = queued ? sc->queue_capacity : 0; qo.count = sc->d_counts + 1;
         qo.overflow = &sc->d_counters->overflow;
         if (first_primary && timed) HIP_TRY(hipEventRecord(sc->ev_pbegin[slot], stream));
-        launch_primary(instrumented, sc->features, grid_primary, stream, sc->d, R, qo, d_out, sc->d_counters, sc->d_spill, tiles_x, tiles_y, sc->d_counts + kMaxGenerations + 2, grab, next_counts, R.first_batch ? next_ctr : nullptr);
+        launch_primary(instrumented, sc->features, occ, grid_primary, stream, sc->d, R, qo, d_out, sc->d_counters, sc->d_spill, tiles_x, tiles_y, sc->d_counts + kMaxGenerations + 2, grab, next_counts, R.first_batch ? next_ctr : nullptr);
         HIP_TRY(hipGetLastError());
         if (first_primary) {
             if (timed) HIP_TRY(hipEventRecord(sc->ev_pend[slot], stream));
@@ -1266,6 +1292,7 @@ int nrays_scene_create(const NraysSceneDesc* desc, NraysScene** out_scene) {
     { const int f = sc->features; // multi-light mesh scenes without double branching: 2, 4 or 8 lanes per pixel in a split tile
       if ((f & kFeatMultiSample) && (f & kFeatMesh) && !(f & kFeatDouble) && h.lights.size() >= 2) { uint32_t l = 1; while (l < 3u && (2u << l) <= h.lights.size()) ++l; sc->light_lsl = l; } }
     if (const char* e = getenv("NRAYS_LIGHT_SPLIT")) sc->light_split_factor = (float)atof(e);
+    if (const char* e = getenv("NRAYS_OCC")) sc->occ_override = atoi(e);
     if (const char* e = getenv("NRAYS_LPT_ANALYTIC")) sc->lpt_analytic = atoi(e) != 0;
     if (const char* e = getenv("NRAYS_LPT_REUSE")) sc->lpt_reuse = atoi(e) != 0;
     if (const char* e = getenv("NRAYS_LEAD_WGS")) sc->lead_mode = atoi(e) != 0;
