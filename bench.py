@@ -59,8 +59,11 @@ def load_workload(name):
         cam = fs.camera_dict()
         return fs, cam, "scenes/balls.scene via the loader3d front-end, %dx%d, refl 0.2 0.25 (4 reflection bounces), 1 ray/pixel, procedural globe.png"
     from tools import standins
-    if name == "hairball":
+    if name in ("hairball", "config5"):
         sc, cam = standins.hairball_scene()
+        if name == "config5":  # BASELINE config 5: 3840x2160, 64 AA samples per pixel in a one-pixel window, counter-based RNG seed 1
+            cam = dict(cam, spp=64, window=1.0, seed=1)
+            return sc, cam, "hairball STAND-IN (procedural, 2.88 M triangles; the real asset is not shipped upstream), %dx%d, 1 light, 64 rays/pixel (aa 64 1.0, BASELINE config 5)"
         return sc, cam, "hairball STAND-IN (procedural, 2.88 M triangles: 3000 strands x 8 sides x 60 segments; the real asset is not shipped upstream), %dx%d, 1 light, 1 ray/pixel"
     sc, cam = standins.sponza_scene(n_lights=8 if name == "config4" else 1)
     return sc, cam, "crytek_sponza STAND-IN (procedural, %d triangles, 276 nodes, alpha-mapped foliage; the real asset is not shipped upstream), " % standins.SPONZA_TRIS + (
@@ -71,7 +74,7 @@ def camera_params(cam, W, H):
     import nrays_amd as nr
     from nrays_amd import math3d
     proj = math3d.inverse_projection(cam["eye"], cam["at"], cam["fovy"], W, H)
-    return nr.make_params((W, H), 1, 0.0, cam["eye"], proj)
+    return nr.make_params((W, H), cam.get("spp", 1), cam.get("window", 0.0), cam["eye"], proj, seed=cam.get("seed", 0))
 
 
 def roofline_block(pk, tst, W, owned_rows, scene_bytes, pmc, pmc_source, tile_costs=None):
@@ -254,7 +257,7 @@ def single_gpu_measure(name, W, H, steps, warmup, args, pmc=True, moving=True):
     dt = time.perf_counter() - t0
     tst = nr.get_stats(scene)
     plain = st  # the instrumented frame's counters: rays_primary_traced (what reached a BVT query) is only counted there
-    res = {"workload": desc % (W, H), "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 5),
+    res = {"workload": desc % (W, H), "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 5), "ray_per_pixel": int(cam.get("spp", 1)),
            "value": round(st.total_rays() * steps / dt / 1e6, 3), "unit": "Mrays/s",
            "steady_state": "resting camera: %d untimed settle frames before --warmup (per-camera cost order decided); kernel_ms from HIP events on every 4th frame" % settle,
            "rays_per_frame": {"total": int(st.total_rays()), "primary": int(st.rays_primary), "reflection": int(st.rays_reflection),
@@ -267,7 +270,7 @@ def single_gpu_measure(name, W, H, steps, warmup, args, pmc=True, moving=True):
            "cold_frame_ms": round(first[0], 4), "second_frame_ms": round(first[1], 4), "third_frame_ms": round(first[2], 4),
            "cold_frame_note": "fresh handle in a warm process (kernels loaded): first scene::render of a camera — no cost history, cost "
                               "recording, raygen tables, per-handle buffer allocation; host-synchronised wall time"}
-    if moving:
+    if moving and cam.get("spp", 1) == 1:
         # a camera that moves every frame (eye shifted by 1e-3 of its distance per frame): cost recording + re-sorting stay on
         import numpy as np
         eye0 = np.array(cam["eye"], dtype=np.float64); at = np.array(cam["at"], dtype=np.float64)
@@ -282,12 +285,17 @@ def single_gpu_measure(name, W, H, steps, warmup, args, pmc=True, moving=True):
     pmc_res, src = (None, None) if (args.no_pmc or not pmc) else pmc_for(name, W, H, live=not args.replay_pmc)
     res["roofline"] = roofline_block(pk, tst, W, H, lib.nrays_scene_device_bytes(handle), pmc_res, src, tile_costs)
     if not args.no_cpu_baseline:
-        res["cpu_baseline"] = cpu_baseline(scene, p, args.cpu_seconds)
+        # bounded sample: a 64-spp 4K frame is ~200 CPU-core-minutes — the CPU leg of config 5 renders the same camera at an eighth
+        # of the resolution in each direction (same scene, same samples per pixel), and says so
+        cp = camera_params(cam, max(W // 8, 1), max(H // 8, 1)) if cam.get("spp", 1) > 1 else p
+        res["cpu_baseline"] = cpu_baseline(scene, cp, args.cpu_seconds)
+        if cp is not p:
+            res["cpu_baseline"]["sample"] += " (the workload's camera at %dx%d)" % (cp.width, cp.height)
         res["gpu_over_cpu"] = round(res["value"] / max(res["cpu_baseline"]["value"], 1e-9), 1)
     return res
 
 
-WORKLOAD_RES = {"config4": (3840, 2160)}  # BASELINE config 4: crytek_sponza 3840x2160, 8 lights
+WORKLOAD_RES = {"config4": (3840, 2160), "config5": (3840, 2160)}  # BASELINE configs 4 (sponza, 8 lights) and 5 (hairball, 64 spp)
 
 
 def main():
@@ -297,7 +305,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--width", type=int, default=0, help="default: 1920 (3840 for --scene config4)")
     ap.add_argument("--height", type=int, default=0, help="default: 1080 (2160 for --scene config4)")
-    ap.add_argument("--scene", default="balls", choices=["balls", "sponza", "hairball", "config4"],
+    ap.add_argument("--scene", default="balls", choices=["balls", "sponza", "hairball", "config4", "config5"],
                     help="balls = BASELINE config 2 (the metric's workload); config4 = crytek_sponza stand-in 3840x2160 with 8 lights")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary blocks (sponza / hairball stand-ins; config 4 at N > 1)")
@@ -355,7 +363,7 @@ def run_single(args):
         "value": m["value"], "unit": "Mrays/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": m["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": m["workload"], "resolution": [W, H], "ray_per_pixel": 1, "parallelism": "1 GPU",
+        "config": {"workload": m["workload"], "resolution": [W, H], "ray_per_pixel": m["ray_per_pixel"], "parallelism": "1 GPU",
                    "rays_per_frame": m["rays_per_frame"], "rays_traced_per_frame": m["rays_traced_per_frame"],
                    "steady_state": m["steady_state"]},
         "value_traced": m["value_traced"],
@@ -463,7 +471,7 @@ def tiled_measure(name, W, H, steps, warmup, rank, world, owners):
         owned = len(tiling.owned_rows(H, band, owner0, owners))
         res = {"value": round(rays_total * steps / dt / 1e6, 3), "unit": "Mrays/s", "steps": steps, "warmup": warmup,
                "ms_per_step": round(dt / steps * 1e3, 5), "value_traced": round(traced * steps / dt / 1e6, 3),
-               "config": {"workload": desc % (W, H), "resolution": [W, H], "ray_per_pixel": 1, "parallelism": mode,
+               "config": {"workload": desc % (W, H), "resolution": [W, H], "ray_per_pixel": int(cam.get("spp", 1)), "parallelism": mode,
                           "tiled_frame_identical_to_single_gpu_render": check,
                           "rays_per_frame": {"total": int(rays_total), "primary": int(rays_t[1].item()), "reflection": int(rays_t[2].item()),
                                              "refraction": int(rays_t[3].item()), "shadow": int(rays_t[4].item())},

@@ -39,7 +39,7 @@ def run_one(scene_name, steps, width, height, check):
         sc, cam = standins.sponza_scene()
     elif scene_name in ("sponza8", "config4"):
         sc, cam = standins.sponza_scene(n_lights=8)
-    elif scene_name == "hairball":
+    elif scene_name in ("hairball", "config5"):
         sc, cam = standins.hairball_scene()
     elif scene_name == "primitives":
         sc, cam = su.primitives_scene(0.0, 1)
@@ -48,7 +48,7 @@ def run_one(scene_name, steps, width, height, check):
     t0 = time.perf_counter()
     h = sc.device_handle()
     t_build = time.perf_counter() - t0
-    p, _ = su.camera_params(cam, width, height)
+    p, _ = su.camera_params(cam, width, height, **(dict(spp=64, window=1.0, seed=1) if scene_name == "config5" else {}))  # config5: aa 64 1.0
     out = torch.empty((height, width, 3), dtype=torch.float32, device="cuda")
 
     def render(instr=False):
