@@ -273,6 +273,11 @@ int nrays_debug_cast_batch(NraysScene* scene, uint32_t mode, uint32_t n, const d
  * a node whose AABB the ray passes, src/scene.rs:276).  out = {min x, y, z, max x, y, z}. */
 int nrays_debug_node_aabb(NraysScene* scene, uint32_t node, double out[6]);
 
+/* How the library classified the scene (test probe): out[0] = kernel permutation it renders with (1 analytic shapes, 2 meshes,
+ * 4 some node may be non-opaque to shadow rays, 16 more than one light sample per hit), out[1] = 1 when a hair-like mesh makes the
+ * BVT queries end their node phases by quorum (NRAYS_NODE_QUORUM=0 in the environment of nrays_scene_create turns that off). */
+int nrays_debug_scene_flags(const NraysScene* scene, uint32_t out[2]);
+
 /* Device bytes of the flattened scene (BVH nodes, triangle records, instance / shading records, textures): what
  * a frame must read at least once — the compulsory part of bench.py's roofline block. */
 uint64_t nrays_scene_device_bytes(const NraysScene* scene);

@@ -186,6 +186,7 @@ extern "C" {
     pub fn nrays_get_stats(scene: *mut NraysScene, out_stats: *mut NraysStats) -> c_int;
     pub fn nrays_get_primary_kernel_stats(scene: *mut NraysScene, out_stats: *mut NraysStats) -> c_int;
     pub fn nrays_debug_node_aabb(scene: *mut NraysScene, node: u32, out: *mut f64) -> c_int;
+    pub fn nrays_debug_scene_flags(scene: *const NraysScene, out: *mut u32) -> c_int;
     pub fn nrays_get_tile_costs(scene: *mut NraysScene, out: *mut NraysTileCosts) -> c_int;
     pub fn nrays_debug_cast_batch(scene: *mut NraysScene, mode: u32, n: u32, origins: *const f64, dirs: *const f64, max_toi: *const f64, out: *mut NraysCastResult) -> c_int;
 

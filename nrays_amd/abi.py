@@ -106,6 +106,7 @@ class NraysCastResult(C.Structure):
 # Every symbol include/nrays_abi.h declares, with its ctypes signature.
 HIP_SYMBOLS = {
     "nrays_debug_node_aabb": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_double)]),
+    "nrays_debug_scene_flags": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "nrays_get_tile_costs": (C.c_int, [C.c_void_p, C.POINTER(NraysTileCosts)]),
     "nrays_debug_cast_batch": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                          C.POINTER(NraysCastResult)]),

@@ -53,7 +53,8 @@ enum InstanceFlags : uint32_t {
                              // for every hit), so the first hit within maxtoi blocks (scene.rs:328-330)
     kInstHasUv = 8u,         // the mesh(es) behind this BLAS carry uvs
     kInstNoXform = 16u,      // identity rotation AND zero translation: local space == world space
-    kInstNoUvValues = 32u    // the node's material never reads the VALUES of u, v (NormalMaterial, untextured Phong): a ball skips atan2 / asin
+    kInstNoUvValues = 32u,   // the node's material never reads the VALUES of u, v (NormalMaterial, untextured Phong): a ball skips atan2 / asin
+    kInstIncoherent = 64u    // hair-like mesh (scene_build.cpp: presplit): neighbouring rays walk different nodes (DScene::incoherent)
 };
 
 // Flags carried in the 3 low bits of a TLAS leaf ref (triangle leaves use them as count - 1).
@@ -178,6 +179,7 @@ struct DScene {
     uint32_t num_planes;
     uint32_t num_lights;
     float background[3];
+    uint32_t incoherent;          // some mesh is hair-like (kInstIncoherent): traverse() ends node phases by quorum
     // Small analytic scenes (no meshes; all records below within kLdsSceneBytes): one packed copy of nodes, instances,
     // links, shading records, node AABBs, lights and plane lists, which the kFeatLdsScene kernels stage into LDS once per
     // workgroup — a dependent record fetch then costs an LDS access instead of a trip through the vector memory path.

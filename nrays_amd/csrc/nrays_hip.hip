@@ -1239,6 +1239,10 @@ int nrays_scene_create(const NraysSceneDesc* desc, NraysScene** out_scene) {
     sc->d.closest_root = h.closest_root; sc->d.shadow_root = h.shadow_root;
     sc->d.num_planes = (uint32_t)h.planes.size(); sc->d.num_lights = (uint32_t)h.lights.size();
     for (int a = 0; a < 3; ++a) sc->d.background[a] = h.background[a];
+    {   // NRAYS_NODE_QUORUM=0 keeps every node phase running until its last lane holds a leaf (A/B switch)
+        const char* e = getenv("NRAYS_NODE_QUORUM");
+        sc->d.incoherent = h.any_incoherent && !(e && atoi(e) == 0) ? 1u : 0u;
+    }
     // stack bound: one deferred sibling per level of TLAS and BLAS, plus the sentinel
     // worst-case stack use: up to 3 deferred siblings per level of TLAS + BLAS (max_bvh_depth bounds each),
     // one sentinel, the plane pseudo-leaves, a little slack; whatever exceeds the LDS part spills to HBM
@@ -1508,6 +1512,12 @@ int nrays_render_rgb8(NraysScene* sc, const NraysRenderParams* p, uint8_t* out_r
         HIP_TRY(hipMemcpy(&overflow, &sc->d_counters->overflow, sizeof overflow, hipMemcpyDeviceToHost));
         if (overflow) return fail(NRAYS_ERR_QUEUE_OVERFLOW, "continuation-ray queue overflow: image is incomplete");
     }
+    return NRAYS_OK;
+}
+
+int nrays_debug_scene_flags(const NraysScene* sc, uint32_t out[2]) {
+    if (!sc || !out) return fail(NRAYS_ERR_BAD_ARG, "null argument");
+    out[0] = (uint32_t)sc->host.features; out[1] = sc->d.incoherent;
     return NRAYS_OK;
 }
 

@@ -128,6 +128,7 @@ void node_world_aabb(const NraysNode& n, const double R[9], const float mesh_mn[
 struct Blas {
     int32_t root;
     float mn[3], mx[3]; // local bounds
+    bool hairy;         // thin diagonal triangles throughout (presplit())
 };
 
 // ---- triangle pre-splitting ----------------------------------------------------------------------
@@ -210,7 +211,7 @@ static double poly_area2(const ClipPoly& p) { // twice the area of a planar conv
 #define NR_PRESPLIT_HAIRY 0.9        // area-weighted emptiness of the mesh above which it counts as hair-like
 #endif
 #ifndef NR_PRIM_COST_HAIRY
-#define NR_PRIM_COST_HAIRY 0.35f
+#define NR_PRIM_COST_HAIRY 0.7f // re-tuned with the quorum-ended node phases of round 3 (0.35 before): hairball 2.36 -> 2.27 ms, 14.6 -> 9.0 triangle tests per ray
 #endif
 #ifndef NR_PRESPLIT_BUDGET_HAIRY
 #define NR_PRESPLIT_BUDGET_HAIRY 5.0 // re-tuned with the cheaper node step of round 2 (3.0 before): hairball 3.06 -> 2.97 ms, 15.1 -> 11.2 triangle tests per ray; 8.0 gives 2.93 ms for twice the references
@@ -389,13 +390,14 @@ int append_blas(const NraysSceneDesc* d, const std::vector<uint32_t>& node_ids, 
     // architectural stand-in is 4 % slower with this value, profiles/r02_nodeloop_ab.log)
     BuiltBvh bvh = build_bvh(pb, NR_MAX_LEAF, hairy ? NR_PRIM_COST_HAIRY : 0.0f);
     auto T2 = std::chrono::steady_clock::now();
-    if (getenv("NRAYS_BUILD_TIMES")) fprintf(stderr, "presplit %.2f s, build_bvh %.2f s (%zu refs)\n", std::chrono::duration<double>(T1 - T0).count(), std::chrono::duration<double>(T2 - T1).count(), pb.size());
+    if (getenv("NRAYS_BUILD_TIMES")) fprintf(stderr, "presplit %.2f s, build_bvh %.2f s (%zu triangles, %zu refs%s)\n", std::chrono::duration<double>(T1 - T0).count(), std::chrono::duration<double>(T2 - T1).count(), recs.size(), pb.size(), hairy ? ", hair-like" : "");
     if (out.tris.size() + pb.size() >= (1u << 28)) { err = "too many triangles"; return NRAYS_ERR_UNSUPPORTED; }
     rebase_bvh(bvh, (int32_t)out.nodes.size(), (uint32_t)out.tris.size());
     out.max_bvh_depth = std::max(out.max_bvh_depth, bvh.max_depth);
     for (uint32_t k : bvh.order) { out.tris.push_back(recs[ref_tri[k]]); out.triuvs.push_back(uvs[ref_tri[k]]); }
     out.nodes.insert(out.nodes.end(), bvh.nodes.begin(), bvh.nodes.end());
     blas.root = bvh.root;
+    blas.hairy = hairy;
     return NRAYS_OK;
 }
 
@@ -585,6 +587,7 @@ int build_host_scene(const NraysSceneDesc* d, HostScene& out, std::string& err) 
             in.flags &= ~(uint32_t)kInstSolid; // TriMesh ignores `solid` (SURVEY B-8)
             in.node_id = sub.size() == 1 ? (int32_t)sub[0] : -1;
             in.blas_root = blas.root;
+            if (blas.hairy) { in.flags |= kInstIncoherent; out.any_incoherent = true; }
             double c[3], h[3];
             for (int a = 0; a < 3; ++a) { c[a] = 0.5 * ((double)blas.mn[a] + (double)blas.mx[a]); h[a] = 0.5 * ((double)blas.mx[a] - (double)blas.mn[a]); }
             PrimBounds b = world_box(info[n0].R, d->nodes[n0].translation, c, h);

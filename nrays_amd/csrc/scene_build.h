@@ -36,6 +36,7 @@ struct HostScene {
     bool any_transparent = false;  // some node can produce alpha != 1 (scene.rs:229)
     bool any_area_light = false;   // some light has radius != 0 (light.rs:60 consumes random numbers)
     bool any_double_branch = false; // some node can spawn BOTH a reflection and a refraction at one hit
+    bool any_incoherent = false;    // some BLAS holds a hair-like mesh (DScene::incoherent)
     bool any_mesh = false;          // some TriMesh node has triangles (decides the tile scheduling path)
     uint32_t reflection_generations = 0; // upper bound from the energy rule (scene.rs:204-206)
     int max_bvh_depth = 0;

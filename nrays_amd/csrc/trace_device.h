@@ -33,8 +33,13 @@ constexpr int kBlock = 256;     // threads per workgroup = 4 wave64 (8-wave work
 #endif
 constexpr int kLdsStack = NR_LDS_STACK;   // traversal-stack entries kept in LDS per lane (then spills to HBM)
 constexpr int32_t kSentinel = (int32_t)0x80000001; // marks "leave the BLAS" on the traversal stack
+constexpr int32_t kParked = (int32_t)0x80000002;   // a lane that yielded its node phase (traverse(): node_quorum); like kEmptyChild / kSentinel not a leaf ref
+                                                   // that can occur (first = 2^28 - 1: scene_build.cpp refuses scenes that large)
 
 #define NR_DEV __device__ __forceinline__
+#ifndef NR_NODE_QUORUM_DEN
+#define NR_NODE_QUORUM_DEN 3 // traverse(): node phases inside a hair-like mesh end below 1 / DEN of the query's lanes (0 = off)
+#endif
 #ifndef NR_SCALAR_NODES
 #define NR_SCALAR_NODES 1 // wave-uniform node visits fetch the node with scalar loads (traverse())
 #endif
@@ -840,6 +845,8 @@ NR_DEV bool traverse(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, Hit&
     const bool GATED = SHADOW || gated_closest;
     constexpr bool kAnalytic = (FEAT & kFeatAnalytic) != 0, kMesh = (FEAT & kFeatMesh) != 0;
     constexpr bool kAlpha = (FEAT & kFeatAlphaShadow) != 0; // shadow mode: otherwise every hit within tlimit blocks
+    // the opaque-mesh kernels only (where hair lives): the three scalar instructions per visit cost the alpha-shadow kernels 2 %
+    constexpr bool kQuorum = NR_NODE_QUORUM_DEN != 0 && kMesh && !kAnalytic && !kAlpha;
     const Instance* insts = SHADOW ? S.shadow_instances : S.instances;
     const InstLink* links = SHADOW ? S.shadow_links : S.links;
     double bt = SHADOW ? tlimit : kDblMax;
@@ -868,6 +875,12 @@ NR_DEV bool traverse(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, Hit&
     NR_TIC(tphase);
     for (;;) {
         NR_TOC(cyc_leaf, tphase);
+        // Scenes with hair-like meshes (DScene::incoherent): the lanes of a wave walk different nodes and reach their leaves after very different
+        // numbers of steps, and a node phase that lasts until the LAST lane holds a leaf leaves most lanes idle (hairball: 11 of 64
+        // lanes active per node step).  There the node phase ends once fewer than a third of the query's lanes are still on internal
+        // nodes; those lanes sit out the leaf phase and step on afterwards.  Results do not depend on the visiting order.  (Coherent
+        // scenes lose: stragglers that fall behind the packet turn its wave-uniform visits into divergent ones; sponza +4 %.)
+        const int node_quorum = kQuorum && S.incoherent ? __popcll(__ballot(1)) / NR_NODE_QUORUM_DEN : 0;
         while (cur >= 0) {
             NR_ITER(wv_node, ln_node);
             NR_UNIFORM(cur);
@@ -933,8 +946,12 @@ NR_DEV bool traverse(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, Hit&
                 }
                 if (cur == kEmptyChild) cur = st.pop();
             }
+            if (kQuorum && node_quorum && __popcll(__ballot(cur >= 0)) < node_quorum) { // wave-uniform
+                if (cur >= 0) { st.push(cur); cur = kParked; } // leaves the node phase through the loop condition, like a lane with a leaf
+            }
         }
         NR_TOC(cyc_node, tphase);
+        if (kQuorum && cur == kParked) { cur = st.pop(); continue; } // sits out the leaf phase of the others
         if (cur == kEmptyChild) break;
         if (kMesh && cur == kSentinel) { // the BLAS of `cur_inst` is exhausted: back to world space
             in_blas = false;
