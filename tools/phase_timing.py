@@ -21,9 +21,10 @@ def main():
     from tools import scenes_util as su, standins
     lib = abi.load_hip_lib()
     for name in sys.argv[1:] or ["sponza", "hairball"]:
+        name, _, spp = name.partition("@")  # hairball@16: anti-aliased, 16 rays per pixel, window 1
         sc, cam = {"sponza": standins.sponza_scene, "hairball": standins.hairball_scene,
                    "sponza8": lambda: standins.sponza_scene(n_lights=8), "balls": su.balls_scene}[name]()
-        p, _ = su.camera_params(cam, 1920, 1080)
+        p, _ = su.camera_params(cam, 1920, 1080, **(dict(spp=int(spp), window=1.0, seed=1) if spp else {}))
         out = torch.empty((1080, 1920, 3), dtype=torch.float32, device="cuda")
         for _ in range(3):
             abi.check(lib.nrays_render_device(sc.device_handle(), C.byref(p), C.c_void_p(out.data_ptr()), None))
@@ -32,7 +33,7 @@ def main():
         dbg = (C.c_ulonglong * 16)()
         lib.nrays_debug_counters.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
         abi.check(lib.nrays_debug_counters(sc.device_handle(), dbg))
-        print(json.dumps({"scene": name, "ms": round(st.kernel_ms_primary, 3), "wave_cycles": st.prim_tests,
+        print(json.dumps({"scene": name, "ray_per_pixel": int(spp or 1), "ms": round(st.kernel_ms_primary, 3), "wave_cycles": st.prim_tests,
                           "node_loops": round(st.node_tests / tot, 3), "leaf_phases": round(st.tri_tests / tot, 3),
                           "triangle_leaves": round(st.hit_records / tot, 3),
                           "outside_traversal": round(1 - (st.node_tests + st.tri_tests) / tot, 3),
