@@ -89,10 +89,11 @@ __device__ __forceinline__ void flush_counters(DeviceCounters* ctr, const Cnt& c
         if (__lane_id() == 0) atomicAdd(&ctr->dbg2[k_], (unsigned long long)x_);
     }
     if (__lane_id() == 0) { atomicAdd(&ctr->dbg[4], (unsigned long long)q0); atomicAdd(&ctr->dbg[5], (unsigned long long)q1); atomicAdd(&ctr->dbg[6], (unsigned long long)q2); atomicAdd(&ctr->dbg[7], (unsigned long long)u0); }
-    unsigned i0 = c.wv_node, i1 = c.ln_node, i2 = c.wv_tri, i3 = c.ln_tri;
+    unsigned i0 = c.wv_node, i1 = c.ln_node, i2 = c.wv_tri, i3 = c.ln_tri, i4 = c.inq_node, i5 = c.inq_tri;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { i0 += __shfl_down(i0, off); i1 += __shfl_down(i1, off); i2 += __shfl_down(i2, off); i3 += __shfl_down(i3, off); }
+    for (int off = 32; off > 0; off >>= 1) { i0 += __shfl_down(i0, off); i1 += __shfl_down(i1, off); i2 += __shfl_down(i2, off); i3 += __shfl_down(i3, off); i4 += __shfl_down(i4, off); i5 += __shfl_down(i5, off); }
     if (__lane_id() == 0) {
+        atomicAdd(&ctr->dbg2[6], (unsigned long long)i4); atomicAdd(&ctr->dbg2[7], (unsigned long long)i5);
         atomicAdd(&ctr->dbg[0], (unsigned long long)i0); atomicAdd(&ctr->dbg[1], (unsigned long long)i1);
         atomicAdd(&ctr->dbg[2], (unsigned long long)i2); atomicAdd(&ctr->dbg[3], (unsigned long long)i3);
         atomicAdd(&ctr->hit_records, (unsigned long long)pt);  // hit_records = triangle leaves (part of the leaf phases)
@@ -198,7 +199,7 @@ __global__ void __launch_bounds__(kBlock, OCC ? OCC : waves_per_simd(FEAT)) k_pr
     st.init();
     Cnt cnt; cnt.node = cnt.tri = cnt.prim = cnt.hit = cnt.tex = cnt.shadow = cnt.refl = cnt.refr = cnt.max_depth = cnt.max_chain_nodes = cnt.traced = 0;
 #ifdef NR_PHASE_TIMING
-    cnt.cyc_node = cnt.cyc_leaf = cnt.cyc_other = cnt.cyc_tri = 0; cnt.wv_node = cnt.ln_node = cnt.wv_tri = cnt.ln_tri = 0; cnt.cyc_closest0 = cnt.cyc_closestN = cnt.cyc_shadow = 0; cnt.wv_uni = 0; for (int k_ = 0; k_ < 8; ++k_) cnt.cyc_x[k_] = 0;
+    cnt.cyc_node = cnt.cyc_leaf = cnt.cyc_other = cnt.cyc_tri = 0; cnt.wv_node = cnt.ln_node = cnt.wv_tri = cnt.ln_tri = 0; cnt.cyc_closest0 = cnt.cyc_closestN = cnt.cyc_shadow = 0; cnt.wv_uni = 0; cnt.inq_node = cnt.inq_tri = 0; for (int k_ = 0; k_ < 8; ++k_) cnt.cyc_x[k_] = 0;
     unsigned long long twave = __builtin_readcyclecounter();
 #endif
 
@@ -430,7 +431,7 @@ __global__ void __launch_bounds__(kBlock, NRAYS_WAVES_PER_SIMD) k_bounce(DScene 
     st.init();
     Cnt cnt; cnt.node = cnt.tri = cnt.prim = cnt.hit = cnt.tex = cnt.shadow = cnt.refl = cnt.refr = cnt.max_depth = cnt.max_chain_nodes = cnt.traced = 0;
 #ifdef NR_PHASE_TIMING
-    cnt.cyc_node = cnt.cyc_leaf = cnt.cyc_other = cnt.cyc_tri = 0; cnt.wv_node = cnt.ln_node = cnt.wv_tri = cnt.ln_tri = 0; cnt.cyc_closest0 = cnt.cyc_closestN = cnt.cyc_shadow = 0; cnt.wv_uni = 0; for (int k_ = 0; k_ < 8; ++k_) cnt.cyc_x[k_] = 0;
+    cnt.cyc_node = cnt.cyc_leaf = cnt.cyc_other = cnt.cyc_tri = 0; cnt.wv_node = cnt.ln_node = cnt.wv_tri = cnt.ln_tri = 0; cnt.cyc_closest0 = cnt.cyc_closestN = cnt.cyc_shadow = 0; cnt.wv_uni = 0; cnt.inq_node = cnt.inq_tri = 0; for (int k_ = 0; k_ < 8; ++k_) cnt.cyc_x[k_] = 0;
 #endif
     uint32_t n = *count_in;
     if (n > capacity) n = capacity;
@@ -467,7 +468,7 @@ __global__ void __launch_bounds__(kBlock, NRAYS_WAVES_PER_SIMD) k_cast_batch(DSc
     st.init();
     Cnt cnt; cnt.node = cnt.tri = cnt.prim = cnt.hit = cnt.tex = cnt.shadow = cnt.refl = cnt.refr = cnt.max_depth = cnt.max_chain_nodes = cnt.traced = 0;
 #ifdef NR_PHASE_TIMING
-    cnt.cyc_node = cnt.cyc_leaf = cnt.cyc_other = cnt.cyc_tri = 0; cnt.wv_node = cnt.ln_node = cnt.wv_tri = cnt.ln_tri = 0; cnt.cyc_closest0 = cnt.cyc_closestN = cnt.cyc_shadow = 0; cnt.wv_uni = 0; for (int k_ = 0; k_ < 8; ++k_) cnt.cyc_x[k_] = 0;
+    cnt.cyc_node = cnt.cyc_leaf = cnt.cyc_other = cnt.cyc_tri = 0; cnt.wv_node = cnt.ln_node = cnt.wv_tri = cnt.ln_tri = 0; cnt.cyc_closest0 = cnt.cyc_closestN = cnt.cyc_shadow = 0; cnt.wv_uni = 0; cnt.inq_node = cnt.inq_tri = 0; for (int k_ = 0; k_ < 8; ++k_) cnt.cyc_x[k_] = 0;
 #endif
     for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
         const uint32_t i = base + threadIdx.x;

@@ -96,12 +96,16 @@ constexpr unsigned long long kSaltPath = 2ULL, kSaltRefl = 0x100ULL, kSaltRefr =
 // wave to traversal phases; lane 0 accumulates, flush_counters sums over waves.
 #define NR_TIC(var) unsigned long long var = __builtin_readcyclecounter()
 #define NR_ITER(wv, ln) { cnt.ln++; if ((int)__lane_id() == __ffsll((long long)__ballot(1)) - 1) cnt.wv++; }
+#define NR_INQ(field, n) { if ((int)__lane_id() == __ffsll((long long)__ballot(1)) - 1) cnt.field += (unsigned)(n); }
+#define NR_INQ_COUNT(var) const int var = __popcll(__ballot(1))
 #define NR_UNIFORM(curv) { const int f_ = __builtin_amdgcn_readfirstlane(curv); const unsigned long long a_ = __ballot(1); if (__ballot((curv) != f_) == 0ULL && (int)__lane_id() == __ffsll((long long)a_) - 1) cnt.wv_uni++; }
 #define NR_TOC(cntfield, var) { unsigned long long now_ = __builtin_readcyclecounter(); cnt.cntfield += (unsigned)(now_ - var); var = now_; }
 #else
 #define NR_TIC(var)
 #define NR_TOC(cntfield, var)
 #define NR_ITER(wv, ln)
+#define NR_INQ(field, n)
+#define NR_INQ_COUNT(var)
 #define NR_UNIFORM(curv)
 #endif
 struct Cnt {
@@ -114,6 +118,7 @@ struct Cnt {
     unsigned cyc_node, cyc_leaf, cyc_other, cyc_tri; // per-wave cycles (valid in lane 0); cyc_tri is part of cyc_leaf
     unsigned wv_node, ln_node, wv_tri, ln_tri;       // iterations of the node loop / triangle loop: per wave (counted by the leading active lane) and per lane
     unsigned wv_uni;                                 // node-loop wave iterations in which every active lane fetches the SAME node
+    unsigned inq_node, inq_tri;                      // lanes still inside the query, summed over the wave iterations of the node / triangle loop
     unsigned cyc_x[8];                               // wave cycles outside the queries (DeviceCounters::dbg2)
     unsigned cyc_closest0, cyc_closestN, cyc_shadow; // wave cycles inside the closest-hit query of primary rays / of continuation rays / inside shadow queries
 #endif
@@ -875,6 +880,7 @@ NR_DEV bool traverse(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, Hit&
     NR_TIC(tphase);
     for (;;) {
         NR_TOC(cyc_leaf, tphase);
+        NR_INQ_COUNT(lanes_in_query);
         // Scenes with hair-like meshes (DScene::incoherent): the lanes of a wave walk different nodes and reach their leaves after very different
         // numbers of steps, and a node phase that lasts until the LAST lane holds a leaf leaves most lanes idle (hairball: 11 of 64
         // lanes active per node step).  There the node phase ends once fewer than a third of the query's lanes are still on internal
@@ -883,6 +889,7 @@ NR_DEV bool traverse(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, Hit&
         const int node_quorum = kQuorum && S.incoherent ? __popcll(__ballot(1)) / NR_NODE_QUORUM_DEN : 0;
         while (cur >= 0) {
             NR_ITER(wv_node, ln_node);
+            NR_INQ(inq_node, lanes_in_query);
             NR_UNIFORM(cur);
             // sort keys: entry distance, +inf for a child the ray cannot enter (absent children always: inverted boxes)
             const float kMiss = __builtin_inff();
@@ -982,6 +989,7 @@ NR_DEV bool traverse(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, Hit&
                 if (k < bits) { tq += 3; p0 = tq[0]; p1 = tq[1]; p2 = tq[2]; }
                 if (STATS) cnt.tri++;
                 NR_ITER(wv_tri, ln_tri);
+                NR_INQ(inq_tri, lanes_in_query);
                 double toi;
                 d3 va = D3(t0.x, t0.y, t0.z), vb = D3(t1.x, t1.y, t1.z), vc = D3(t2.x, t2.y, t2.z);
                 if (cast_triangle(va, vb, vc, co, cd, toi, nullptr, nullptr) &&

@@ -43,8 +43,10 @@ def main():
                                                                                                       "shadow_ray_setup", "material", "weights_and_continuation"])},
                           "node_loop_wave_iterations_with_one_node_for_the_whole_wave": round(dbg[7] / max(dbg[0], 1), 3),
                           "node_loop": {"wave_iterations": dbg[0], "lane_iterations": dbg[1], "simd_efficiency": round(dbg[1] / max(64 * dbg[0], 1), 3),
+                                        "lanes_still_in_the_query": round(dbg[14] / max(64 * dbg[0], 1), 3),
                                         "cycles_per_wave_iteration": round(st.node_tests / max(dbg[0], 1))},
                           "triangle_loop": {"wave_iterations": dbg[2], "lane_iterations": dbg[3], "simd_efficiency": round(dbg[3] / max(64 * dbg[2], 1), 3),
+                                            "lanes_still_in_the_query": round(dbg[15] / max(64 * dbg[2], 1), 3),
                                             "cycles_per_wave_iteration": round(st.hit_records / max(dbg[2], 1))}}), flush=True)
 
 
