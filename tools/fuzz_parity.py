@@ -92,13 +92,50 @@ def random_mesh_scene(seed):
     return nr.Scene(nodes, lights, tuple(rng.uniform(0, 1, 3))), cam, rng
 
 
+def random_hair_scene(seed):
+    """Opaque scenes of thin strands (the opaque-mesh kernels with quorum-ended node phases, DScene::incoherent): one to three
+    strand meshes, some sharing an isometry, some rotated, reflective ones among them, sometimes an ordinary mesh beside them;
+    one to three lights, one of them sometimes an area light."""
+    rng = np.random.default_rng(seed)
+    nodes = []
+    isos = [nr.Isometry3((0.0, 0.0, 0.0)), nr.Isometry3(tuple(rng.uniform(-1, 1, 3)), tuple(rng.uniform(-1.0, 1.0, 3)))]
+    for k in range(int(rng.integers(1, 4))):
+        ns, seg = int(rng.integers(20, 160)), int(rng.integers(3, 12))
+        width = float(rng.choice([0.004, 0.01, 0.03]))
+        start = rng.normal(0, 1, (ns, 3)); start /= np.linalg.norm(start, axis=1, keepdims=True)
+        pts = [start * float(rng.uniform(0.3, 1.0))]
+        dirn = start + rng.normal(0, 0.6, (ns, 3))
+        for _ in range(seg):
+            dirn = dirn + rng.normal(0, 0.5, (ns, 3)); dirn /= np.linalg.norm(dirn, axis=1, keepdims=True)
+            pts.append(pts[-1] + dirn * float(rng.uniform(0.1, 0.4)))
+        pts = np.stack(pts, 1)                                  # ns x (seg + 1) x 3: the strands' centre lines
+        side = np.cross(dirn, rng.normal(0, 1, (ns, 3))); side /= np.linalg.norm(side, axis=1, keepdims=True)
+        a, b = pts - side[:, None, :] * width, pts + side[:, None, :] * width
+        tri = np.concatenate([np.stack([a[:, :-1], b[:, :-1], a[:, 1:]], 2), np.stack([b[:, :-1], b[:, 1:], a[:, 1:]], 2)], 1)
+        tri = su.f32_exact(tri.reshape(-1, 3))
+        nt = len(tri) // 3
+        idx = np.arange(3 * nt, dtype=np.uint32).reshape(nt, 3)
+        mat = nr.PhongMaterial(tuple(rng.uniform(0, 0.3, 3)), tuple(rng.uniform(0.2, 1, 3)), tuple(rng.uniform(0, 1, 3)), None, None, float(rng.choice([5.0, 30.0, 100.0])))
+        nodes.append(nr.SceneNode(mat, float(rng.choice([0.0, 0.0, 0.3])), 0.4, 1.0, 1.0, isos[int(rng.integers(0, 2))], nr.TriMesh(tri, idx, None)))
+    if rng.random() < 0.5:
+        p3, i3, uv3 = su.torus_mesh(24, 12)
+        nodes.append(nr.SceneNode(su.default_material(), float(rng.choice([0.0, 0.4])), 0.4, 1.0, 1.0,
+                                  nr.Isometry3(tuple(rng.uniform(-1, 1, 3) + np.array([0.0, -1.5, 0.0]))), nr.TriMesh(p3, i3, uv3)))
+    lights = []
+    for _ in range(int(rng.choice([1, 1, 2, 3]))):
+        rad = float(rng.choice([0.0, 0.0, 0.4]))
+        lights.append(nr.Light(tuple(rng.uniform(-6, 6, 3) + np.array([0, 6, -4])), rad, int(rng.choice([1, 2])) if rad > 0 else 1, tuple(rng.uniform(0.3, 1.0, 3))))
+    cam = dict(eye=tuple(rng.uniform(-1, 1, 3) + np.array([0.0, 0.5, -7.0])), at=(0.0, 0.0, 0.0), fovy=float(rng.choice([30.0, 45.0])))
+    return nr.Scene(nodes, lights, tuple(rng.uniform(0, 1, 3))), cam, rng
+
+
 def main():
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 24
-    worst, bad = 0.0, 0
+    worst, bad, quorum_scenes = 0.0, 0, 0
     for seed in range(first, first + count):
         try:
-            sc, cam, rng = random_mesh_scene(seed) if seed % 2 else random_scene(seed)
+            sc, cam, rng = random_hair_scene(seed) if seed % 3 == 2 else (random_mesh_scene(seed) if seed % 2 else random_scene(seed))
         except AttributeError as e:
             print("scene construction needs attribute:", e); return 2
         w, h = int(rng.integers(40, 200)), int(rng.integers(30, 140))
@@ -108,6 +145,9 @@ def main():
         p, _ = su.camera_params(cam, w, h, **kw)
         ref, ost = oracle.render(sc.descriptor, p, 32)
         out = torch.empty((h, w, 3), dtype=torch.float32, device="cuda")
+        flags = (C.c_uint32 * 2)()
+        abi.check(lib.nrays_debug_scene_flags(sc.device_handle(), flags))
+        quorum_scenes += 1 if (flags[1] and (flags[0] & 7) == 2) else 0
         for rep in range(2):  # second frame runs through the cost-ordered work lists
             abi.check(lib.nrays_render_device(sc.device_handle(), C.byref(p), C.c_void_p(out.data_ptr()), None))
             st = nr.get_stats(sc)
@@ -118,7 +158,7 @@ def main():
             bad += 0 if ok else 1
             print("seed %d frame %d %dx%d spp %d nodes %d lights %d rays %d: max err %.3g counts %s %s" % (
                 seed, rep, w, h, spp, len(sc._nodes), len(sc._lights), st.total_rays(), err, "equal" if same else "DIFFER", "" if ok else "<-- MISMATCH"), flush=True)
-    print("worst error %.3g over %d cases, %d mismatches" % (worst, 2 * count, bad))
+    print("worst error %.3g over %d cases, %d mismatches; %d scenes rendered with quorum-ended node phases" % (worst, 2 * count, bad, quorum_scenes))
     return 1 if bad else 0
 
 
