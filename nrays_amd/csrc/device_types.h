@@ -228,6 +228,7 @@ struct DRender {
     // descending order of the previous frame's cost (read; null = image order).  Scheduling only.
     uint32_t* tile_cost;
 #ifdef NR_DEBUG_TILE_COSTS
+    uint32_t dbg_mode;    // tuning builds: 1 = wave_times[1] holds the wave's work-tile cycles / 16 (26 bits) and its number of work tiles (6 bits)
     uint32_t* wave_times; // tuning builds: per wave {kernel entry, first tile, exit} in 10 ns ticks (s_memrealtime) and its tile count
 #endif
     const uint32_t* tile_order;

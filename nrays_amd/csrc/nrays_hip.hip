@@ -31,6 +31,9 @@
 #include "scene_build.h"
 #include "trace_device.h"
 
+#ifndef NR_NT_STORES
+#define NR_NT_STORES 1 // frame-buffer stores carry the non-temporal hint: the 25 MB of a 1080p frame do not sweep the scene out of the L2s
+#endif
 namespace nrays {
 
 #ifndef NRAYS_WAVES_PER_SIMD
@@ -128,7 +131,10 @@ constexpr int waves_per_simd(int feat) { return (feat & ~(kFeatMultiSample | kFe
 // One row of the compact frame buffer outside the window of blocks that can see the scene (k_primary): background sums
 // (padding rows of the last band: zero) for the floats t0, t0 + tstep, ... of the row.  Out of line: its registers and
 // uniforms stay out of the tile loop's allocation.
-__device__ __noinline__ void fill_background_row(float bg0, float bg1, float bg2, uint32_t spp, float* out, uint32_t width, uint32_t height,
+// INL: the copy inside the tile loop of the workgroup-list kernels is inlined — a call returns through `s_waitcnt vmcnt(0)`, i.e. waits
+// for the row's stores to be acknowledged (1.3 us per quarter row, 6 us at the end of a frame: 20 us of the 45 us balls launch were
+// workgroups finishing their rows one acknowledged call after the other).
+__device__ __attribute__((always_inline)) inline void fill_background_row_body(float bg0, float bg1, float bg2, uint32_t spp, float* out, uint32_t width, uint32_t height,
                                                  uint32_t band_rows, uint32_t band_owner, uint32_t band_owners, uint32_t win_x0, uint32_t win_nx,
                                                  uint32_t win_y0, uint32_t win_ny, uint32_t lane_log2, uint32_t rl, uint32_t t0, uint32_t tstep) {
     const uint32_t bwl = lane_log2 ? (7u - lane_log2) >> 1 : 4u, bhl = lane_log2 ? (6u - lane_log2) >> 1 : 4u;
@@ -140,11 +146,38 @@ __device__ __noinline__ void fill_background_row(float bg0, float bg1, float bg2
     const bool real = j < height;
     const bool split = rl >= wr0 && rl < wr1 && win_nx != 0u; // this row crosses the window: skip its columns
     __attribute__((address_space(1))) float* row = (__attribute__((address_space(1))) float*)(out + (size_t)rl * width * 3);
+    if (!real) { b0 = 0.0f; b1 = 0.0f; b2 = 0.0f; }
+    if (((width * 3u) & 3u) == 0u && (((uintptr_t)out) & 15u) == 0u && (tstep % 3u) == 1u) {
+        // 16-byte stores: chunk q holds the floats 4q .. 4q + 3, i.e. the channels (q mod 3), (q + 1) mod 3, ... — three patterns, and
+        // q mod 3 advances by one per step because tstep = 1 (mod 3).  (The scalar loop below spent a division and a 4-byte store per
+        // float: ~1.5 us per call, and the rows of a workgroup whose waves sit on long tiles were the tail of the balls frame.)
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        const f4v pat[3] = {f4v{b0, b1, b2, b0}, f4v{b1, b2, b0, b1}, f4v{b2, b0, b1, b2}};
+        const uint32_t nq = width * 3u / 4u, f_lo = 3u * wi0, f_hi = 3u * wi1; // floats [f_lo, f_hi) belong to the window
+        uint32_t ph = t0 % 3u;
+        for (uint32_t q = t0; q < nq; q += tstep, ph = ph == 2u ? 0u : ph + 1u) {
+            const uint32_t f = 4u * q;
+            const f4v v = ph == 0u ? pat[0] : (ph == 1u ? pat[1] : pat[2]);
+#if NR_NT_STORES
+            if (!split || f + 4u <= f_lo || f >= f_hi) { __builtin_nontemporal_store(v, (__attribute__((address_space(1))) f4v*)(row + f)); continue; }
+#else
+            if (!split || f + 4u <= f_lo || f >= f_hi) { *(__attribute__((address_space(1))) f4v*)(row + f) = v; continue; }
+#endif
+            for (uint32_t k = 0; k < 4u; ++k) if (f + k < f_lo || f + k >= f_hi) row[f + k] = v[k]; // a chunk across the window's edge
+        }
+        return;
+    }
     for (uint32_t f = t0; f < width * 3u; f += tstep) {
         const uint32_t i = f / 3u, c = f - i * 3u;
         if (split && i >= wi0 && i < wi1) continue;
-        row[f] = real ? (c == 0u ? b0 : (c == 1u ? b1 : b2)) : 0.0f;
+        row[f] = c == 0u ? b0 : (c == 1u ? b1 : b2);
     }
+}
+
+__device__ __noinline__ void fill_background_row(float bg0, float bg1, float bg2, uint32_t spp, float* out, uint32_t width, uint32_t height,
+                                                 uint32_t band_rows, uint32_t band_owner, uint32_t band_owners, uint32_t win_x0, uint32_t win_nx,
+                                                 uint32_t win_y0, uint32_t win_ny, uint32_t lane_log2, uint32_t rl, uint32_t t0, uint32_t tstep) {
+    fill_background_row_body(bg0, bg1, bg2, spp, out, width, height, band_rows, band_owner, band_owners, win_x0, win_nx, win_y0, win_ny, lane_log2, rl, t0, tstep);
 }
 
 // OCC != 0: the alpha-shadow mesh permutations also exist at three waves per SIMD (168 VGPRs, ~64 dwords of scratch per lane): a
@@ -207,7 +240,8 @@ __global__ void __launch_bounds__(kBlock, OCC ? OCC : waves_per_simd(FEAT)) k_pr
     constexpr bool kLightSplit = !STATS && (FEAT & kFeatMultiSample) && (FEAT & kFeatMesh) && !(FEAT & kFeatDouble);
 #ifdef NR_DEBUG_TILE_COSTS
     const uint32_t dbg_t_entry = (uint32_t)__builtin_amdgcn_s_memrealtime();
-    uint32_t dbg_t_first = 0u, dbg_tiles = 0u;
+    const unsigned long long dbg_c_entry = __builtin_readcyclecounter();
+    uint32_t dbg_t_first = 0u, dbg_tiles = 0u, dbg_work_tiles = 0u, dbg_work_cycles = 0u, dbg_t_last_end = 0u, dbg_row_ticks = 0u, dbg_rows = 0u;
 #endif
     // Sample-major lane mapping of anti-aliased frames (ray_per_pixel >= 2): 2^lane_log2 lanes share ONE pixel and trace
     // its samples side by side, so a wave covers 64 >> lane_log2 pixels (8x4, 4x4, 4x2, 2x2, 2x1, 1x1) instead of 8x8 and
@@ -228,6 +262,10 @@ __global__ void __launch_bounds__(kBlock, OCC ? OCC : waves_per_simd(FEAT)) k_pr
     auto fill_row = [&](uint32_t rl, uint32_t t0, uint32_t tstep) { // threads t0, t0 + tstep, ... of the row's W * 3 floats
         fill_background_row(S.background[0], S.background[1], S.background[2], R.spp, out, R.width, R.height, R.band_rows, R.band_owner, R.band_owners,
                             R.win_x0, R.win_nx, R.win_y0, R.win_ny, lane_log2, rl, t0, tstep);
+    };
+    auto fill_row_inline = [&](uint32_t rl, uint32_t t0, uint32_t tstep) { // the same, without a call (and its wait for the stores)
+        fill_background_row_body(S.background[0], S.background[1], S.background[2], R.spp, out, R.width, R.height, R.band_rows, R.band_owner, R.band_owners,
+                                 R.win_x0, R.win_nx, R.win_y0, R.win_ny, lane_log2, rl, t0, tstep);
     };
     if (fill_rows && grab != 0u)
         for (uint32_t rl = blockIdx.x; rl < R.rows_local; rl += gridDim.x) fill_row(rl, threadIdx.x, kBlock);
@@ -265,7 +303,13 @@ __global__ void __launch_bounds__(kBlock, OCC ? OCC : waves_per_simd(FEAT)) k_pr
               const uint32_t part = kk - nhb - ncb;
               const uint32_t rl = (part >> 2) * G + b;
               if (rl >= R.rows_local) break;
-              fill_row(rl, (part & 3u) * 64u + lane, kBlock);
+#ifdef NR_DEBUG_TILE_COSTS
+              { const uint32_t tr0 = (uint32_t)__builtin_amdgcn_s_memrealtime();
+                fill_row_inline(rl, (part & 3u) * 64u + lane, kBlock);
+                dbg_row_ticks += (uint32_t)__builtin_amdgcn_s_memrealtime() - tr0; dbg_rows++; }
+#else
+              fill_row_inline(rl, (part & 3u) * 64u + lane, kBlock);
+#endif
               continue;
           }
           // with the costs of an earlier frame of this camera: entry e of the descending-cost order instead of wave tile e,
@@ -305,9 +349,12 @@ __global__ void __launch_bounds__(kBlock, OCC ? OCC : waves_per_simd(FEAT)) k_pr
         // (an entry of a cost-ordered list may stand for one part of a light-parallel tile: DRender::light_lsl)
         const uint32_t wt = kLightSplit ? (ent & kEntryTileMask) : ent;
         const uint32_t lsl = (kLightSplit && (ent & kEntrySplit)) ? R.light_lsl : 0u, part = kLightSplit ? ((ent >> 28) & 7u) : 0u; // wave-uniform
-        const unsigned long long tile_t0 = R.tile_cost ? __builtin_readcyclecounter() : 0ULL;
 #ifdef NR_DEBUG_TILE_COSTS
+        const unsigned long long tile_t0 = __builtin_readcyclecounter();
+        bool dbg_worked = false;
         if (dbg_tiles++ == 0u) dbg_t_first = (uint32_t)__builtin_amdgcn_s_memrealtime();
+#else
+        const unsigned long long tile_t0 = R.tile_cost ? __builtin_readcyclecounter() : 0ULL;
 #endif
         uint32_t i, rl; // column, local (compact) row
         uint32_t q = 0u; // which of the pixel's side-by-side samples this lane traces
@@ -365,6 +412,9 @@ __global__ void __launch_bounds__(kBlock, OCC ? OCC : waves_per_simd(FEAT)) k_pr
                 // instrumented renders only: a uniform counter in the tile loop of the plain kernels costs 25 us of the 52 us balls
                 // frame (profiles/r03 notes)
                 if (STATS && sample_active) cnt.traced++;
+#ifdef NR_DEBUG_TILE_COSTS
+                dbg_worked = true;
+#endif
                 c = trace_chain<STATS, FEAT>(S, st, sample_active, ray, 0u, R.max_depth, qo, cnt, !PLAIN && R.use_rng != 0u, lsl);
             }
             if (STATS) { unsigned dn = cnt.node - node_before; if (dn > cnt.max_chain_nodes) cnt.max_chain_nodes = dn; }
@@ -380,11 +430,18 @@ __global__ void __launch_bounds__(kBlock, OCC ? OCC : waves_per_simd(FEAT)) k_pr
         if (active && (q != 0u || (lane & ((1u << lsl) - 1u)) != 0u)) { /* the group's first lane writes the pixel */ }
         else if (active) {
             float* o = out + (size_t)pix * 3;
+#if NR_NT_STORES
+            __builtin_nontemporal_store(tot.x, o); __builtin_nontemporal_store(tot.y, o + 1); __builtin_nontemporal_store(tot.z, o + 2);
+#else
             o[0] = tot.x; o[1] = tot.y; o[2] = tot.z;
+#endif
         } else if (q == 0u && (lane & ((1u << lsl) - 1u)) == 0u && i < R.width && rl < R.rows_local && (PLAIN || R.first_batch)) { // padding rows of the last band
             float* o = out + (size_t)pix * 3;
             o[0] = 0.0f; o[1] = 0.0f; o[2] = 0.0f;
         }
+#ifdef NR_DEBUG_TILE_COSTS
+        if (dbg_worked) { dbg_work_tiles++; dbg_work_cycles += (uint32_t)((__builtin_readcyclecounter() - tile_t0) >> 4); dbg_t_last_end = (uint32_t)__builtin_amdgcn_s_memrealtime(); }
+#endif
         if (R.tile_cost && lane == 0u && part == 0u) { // wave cycles spent on this tile, for the next frame's order
             unsigned long long dt = ((__builtin_readcyclecounter() - tile_t0) >> 4) << lsl; // (a light-parallel tile: its first part stands for all)
             R.tile_cost[wt] = dt > 0xffffffffULL ? 0xffffffffu : (uint32_t)dt;
@@ -399,7 +456,7 @@ __global__ void __launch_bounds__(kBlock, OCC ? OCC : waves_per_simd(FEAT)) k_pr
     if (R.wave_times && lane == 0u) {
         uint32_t* w = R.wave_times + 4u * (blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6));
         uint32_t hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        w[0] = dbg_t_entry; w[1] = dbg_t_first; w[2] = (uint32_t)__builtin_amdgcn_s_memrealtime(); w[3] = dbg_tiles | (xcc_id() << 28) | ((hw & 0xffffu) << 12);
+        w[0] = dbg_t_entry; w[1] = R.dbg_mode == 4u ? (dbg_row_ticks & 0xfffffu) | (dbg_rows << 20) : R.dbg_mode == 3u ? dbg_t_last_end : R.dbg_mode == 2u ? (uint32_t)((__builtin_readcyclecounter() - dbg_c_entry) >> 4) : R.dbg_mode ? (dbg_work_cycles & 0x03ffffffu) | (dbg_work_tiles << 26) : dbg_t_first; w[2] = (uint32_t)__builtin_amdgcn_s_memrealtime(); w[3] = dbg_tiles | (xcc_id() << 28) | ((hw & 0xffffu) << 12);
     }
 #endif
     flush_counters(ctr, cnt, STATS);
@@ -1115,7 +1172,7 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
 #ifdef NR_DEBUG_TILE_COSTS
     if (!sc->d_wave_times) HIP_TRY(hipMalloc((void**)&sc->d_wave_times, (size_t)kMaxGrid * (kBlock / 64) * 4 * sizeof(uint32_t)));
     HIP_TRY(hipMemsetAsync(sc->d_wave_times, 0, (size_t)kMaxGrid * (kBlock / 64) * 4 * sizeof(uint32_t), stream));
-    R.wave_times = sc->d_wave_times; sc->dbg_grid = grid_primary;
+    R.wave_times = sc->d_wave_times; sc->dbg_grid = grid_primary; R.dbg_mode = getenv("NRAYS_DEBUG_WAVE_WORK") ? (uint32_t)atoi(getenv("NRAYS_DEBUG_WAVE_WORK")) : 0u;
 #endif
     if (R.tile_cost) { sc->cost_tiles = lane_log2 ? win_units : win_units * 4u; sc->cost_grid = grid_primary; }
     bool first_primary = true;

@@ -548,7 +548,25 @@ NR_DEV f4 tex_sample(const ShadeTex& t, double u, double v, Cnt& cnt) {
     float sx = ux - (float)lx, sy = uy - (float)ly;
     if (hx > wm) hx = wm;
     if (hy > hm) hy = hm;
-    f4 ul = tex_at(t, lx, hy), ur = tex_at(t, hx, hy), dr = tex_at(t, hx, ly), dl = tex_at(t, lx, ly);
+    // the four taps under ONE test of the texel format: inside tex_at each tap is a branch with its own load and its own wait for it —
+    // four memory round trips in a row where one is needed (the deep reflection tiles of the balls frame spent 40 % of their time in
+    // this function; issuing the loads even earlier, before the shadow query of the hit, was measured and buys nothing more)
+    f4 ul, ur, dr, dl;
+    const size_t i_ul = (size_t)hy * t.width + lx, i_ur = (size_t)hy * t.width + hx, i_dr = (size_t)ly * t.width + hx, i_dl = (size_t)ly * t.width + lx;
+    if ((t.mode & 0xffu) == NRAYS_TEXEL_RGBA8) {
+        const __attribute__((address_space(1))) uint32_t* tp = (const __attribute__((address_space(1))) uint32_t*)t.texels;
+        const uint32_t p0 = tp[i_ul], p1 = tp[i_ur], p2 = tp[i_dr], p3 = tp[i_dl];
+        const double k = 1.0 / 255.0; // tex_at: the f64 product rounded to f32 is the correctly rounded `u8 as f32 / 255.0`
+        auto unpack = [&](uint32_t p) { f4 r; r.x = (float)((double)(p & 0xffu) * k); r.y = (float)((double)((p >> 8) & 0xffu) * k);
+                                         r.z = (float)((double)((p >> 16) & 0xffu) * k); r.w = (float)((double)(p >> 24) * k); return r; };
+        ul = unpack(p0); ur = unpack(p1); dr = unpack(p2); dl = unpack(p3);
+    } else {
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        const __attribute__((address_space(1))) f4v* tp = (const __attribute__((address_space(1))) f4v*)t.texels;
+        const f4v q0 = tp[i_ul], q1 = tp[i_ur], q2 = tp[i_dr], q3 = tp[i_dl];
+        ul.x = q0.x; ul.y = q0.y; ul.z = q0.z; ul.w = q0.w; ur.x = q1.x; ur.y = q1.y; ur.z = q1.z; ur.w = q1.w;
+        dr.x = q2.x; dr.y = q2.y; dr.z = q2.z; dr.w = q2.w; dl.x = q3.x; dl.y = q3.y; dl.z = q3.z; dl.w = q3.w;
+    }
     f4 ui, di, r;
     ui.x = ul.x * (1.0f - sx) + ur.x * sx; ui.y = ul.y * (1.0f - sx) + ur.y * sx; ui.z = ul.z * (1.0f - sx) + ur.z * sx; ui.w = ul.w * (1.0f - sx) + ur.w * sx;
     di.x = dl.x * (1.0f - sx) + dr.x * sx; di.y = dl.y * (1.0f - sx) + dr.y * sx; di.z = dl.z * (1.0f - sx) + dr.z * sx; di.w = dl.w * (1.0f - sx) + dr.w * sx;

@@ -16,7 +16,7 @@ frames = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 sc, cam = {"sponza": standins.sponza_scene, "hairball": standins.hairball_scene, "balls": su.balls_scene,
            "ballsfar": lambda: (su.balls_scene()[0], dict(su.balls_scene()[1], eye=(0.0, 150.0, -300.0))),
            "primitives": lambda: su.primitives_scene(0.0, 1)}[name]()
-p, _ = su.camera_params(cam, 1920, 1080)
+p, _ = su.camera_params(cam, 1920, 1080, **({"max_depth": int(sys.argv[3])} if len(sys.argv) > 3 else {}))  # optional third argument: max_depth
 out = torch.empty((1080, 1920, 3), dtype=torch.float32, device="cuda")
 lib.nrays_debug_wave_times.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
 for f in range(frames):
@@ -25,6 +25,44 @@ for f in range(frames):
     abi.check(lib.nrays_debug_wave_times(sc.device_handle(), buf.ctypes.data, 8192, C.byref(n)))
     w = buf[:n.value].astype(np.int64)
     w = w[w[:, 2] != 0]
+    if os.environ.get("NRAYS_DEBUG_WAVE_WORK") == "4":  # w[:, 1] = 10 ns ticks inside fill_row (20 bits) | row entries << 20
+        t0 = w[:, 0].min()
+        ex = (w[:, 2] - t0) / 100.0
+        rt, rn = (w[:, 1] & 0xfffff) / 100.0, w[:, 1] >> 20
+        last = np.argsort(ex)[::-1][:6]
+        print(json.dumps({"scene": name, "frame": f, "span_us": round(float(ex.max()), 1), "row_entries_per_wave_p50_90_100": [float(x) for x in np.percentile(rn, [50, 90, 100])],
+                          "row_us_per_wave_p50_90_100": [round(float(x), 1) for x in np.percentile(rt, [50, 90, 100])],
+                          "last_waves": [{"exit_us": round(float(ex[i]), 1), "row_entries": int(rn[i]), "row_us": round(float(rt[i]), 1), "entries": int(w[i, 3] & 0xfff)} for i in last]}), flush=True)
+        continue
+    if os.environ.get("NRAYS_DEBUG_WAVE_WORK") == "3":  # w[:, 1] = when the wave's last work tile ended (0: it had none)
+        t0 = w[:, 0].min()
+        ex = (w[:, 2] - t0) / 100.0
+        had = w[:, 1] != 0
+        le = np.where(had, (w[:, 1] - t0) / 100.0, np.nan)
+        tail = ex - le
+        last = np.argsort(ex)[::-1][:6]
+        print(json.dumps({"scene": name, "frame": f, "span_us": round(float(ex.max()), 1), "waves_with_work": int(had.sum()),
+                          "last_work_tile_end_us_p50_90_99_100": [round(float(x), 1) for x in np.nanpercentile(le, [50, 90, 99, 100])],
+                          "exit_after_last_work_tile_us_p0_50_90_100": [round(float(x), 1) for x in np.nanpercentile(tail, [0, 50, 90, 100])],
+                          "last_waves": [{"exit_us": round(float(ex[i]), 1), "last_work_tile_end_us": round(float(le[i]), 1), "entries": int(w[i, 3] & 0xfff)} for i in last]}), flush=True)
+        continue
+    if os.environ.get("NRAYS_DEBUG_WAVE_WORK") == "2":  # w[:, 1] = the wave's whole life in s_memtime ticks / 16
+        life_us = (w[:, 2] - w[:, 0]) / 100.0
+        mhz = w[:, 1] * 16 / np.maximum(life_us, 1e-3)
+        print(json.dumps({"scene": name, "frame": f, "s_memtime_ticks_per_us_p0_50_100": [round(float(x), 1) for x in np.percentile(mhz, [0, 50, 100])]}), flush=True)
+        continue
+    if os.environ.get("NRAYS_DEBUG_WAVE_WORK"):  # w[:, 1] = work-tile cycles / 16 (26 bits) | work tiles << 26
+        t0 = w[:, 0].min()
+        ex = (w[:, 2] - t0) / 100.0
+        wc, wt = (w[:, 1] & 0x03ffffff) * 16 / 2400.0, w[:, 1] >> 26   # us at 2.4 GHz, tiles
+        last = np.argsort(ex)[::-1][:6]
+        print(json.dumps({"scene": name, "frame": f, "span_us": round(float(ex.max()), 1),
+                          "work_tiles_per_wave_p50_90_99_100": [float(x) for x in np.percentile(wt, [50, 90, 99, 100])],
+                          "work_us_per_wave_p50_90_99_100": [round(float(x), 1) for x in np.percentile(wc, [50, 90, 99, 100])],
+                          "corr_exit_vs_work_us": round(float(np.corrcoef(ex, wc)[0, 1]), 3),
+                          "exit_minus_work_us_p0_50_100": [round(float(x), 1) for x in np.percentile(ex - wc, [0, 50, 100])],
+                          "last_waves": [{"exit_us": round(float(ex[i]), 1), "work_us": round(float(wc[i]), 1), "work_tiles": int(wt[i]), "entries": int(w[i, 3] & 0xfff)} for i in last]}), flush=True)
+        continue
     hw = w[:, 3] >> 12; w[:, 3] &= 0xfff  # xcc << 16 | HW_ID[15:0] (gfx9: cu_id 11:8, sh_id 12, se_id 15:13)
     cu = (hw >> 8) & 0xfff  # xcc, se, sh, cu: one value per CU
     wg = np.arange(len(w)) // 4
