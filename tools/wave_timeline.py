@@ -77,6 +77,8 @@ for f in range(frames):
     ent, first, ex = (w[:, 0] - t0) / 100.0, np.where(w[:, 3] > 0, (w[:, 1] - t0) / 100.0, np.nan), (w[:, 2] - t0) / 100.0
     q = lambda a: [round(float(x), 1) for x in np.nanpercentile(a, [0, 50, 90, 99, 100])]
     last = np.argsort(ex)[-3:][::-1]
-    print(json.dumps({"scene": name, "frame": f, "waves": int(len(w)), "span_us": round(float(ex.max()), 1),
+    import nrays_amd as _nr
+    _st = _nr.get_stats(sc)
+    print(json.dumps({"scene": name, "frame": f, "waves": int(len(w)), "span_us": round(float(ex.max()), 1), "kernel_ms_primary_of_the_last_timed_frame": round(_st.kernel_ms_primary, 4),
                       "entry_us_p0_50_90_99_100": q(ent), "first_tile_us": q(first), "exit_us": q(ex),
                       "cus": len(pairs), "cus_with_exactly_one_of_the_first_256_workgroups": lead, "waves_whose_simd_id_equals_their_index_in_the_workgroup": round(simd_is_wave_index, 3), "simd_id_histogram": simd_hist, "workgroups_by_number_of_distinct_simd_ids": distinct_hist, "last_waves": [{"exit_us": round(float(ex[i]), 1), "entry_us": round(float(ent[i]), 1), "tiles": int(w[i, 3])} for i in last]}), flush=True)
