@@ -19,6 +19,7 @@ At N = 1 the line also carries
                  fp64_issue_frac, l2_gbs, compulsory_bytes — from rocprofv3 --pmc passes run live by this script
                  (traffic_source says whether the counters are live or replayed from profiles/);
   scene_build_s, cold_frame_ms, moving_camera_ms_per_frame   what a caller pays besides the resting-camera steady state
+  two_frames_in_flight_ms_per_frame   two handles / streams / frame buffers alternating (information; never `value`)
                  the contract's loop times (the reference's only caller renders each camera ONCE);
   value_traced   the rate on the rays that went through a BVT query (wave tiles outside the scene's screen bounds are
                  written without one);
@@ -282,6 +283,27 @@ def single_gpu_measure(name, W, H, steps, warmup, args, pmc=True, moving=True):
             render_on(handle, q)
         torch.cuda.synchronize()
         res["moving_camera_ms_per_frame"] = round((time.perf_counter() - t0) / frames * 1e3, 5)
+    if moving and cam.get("spp", 1) == 1:
+        # two frames in flight: a second handle of the same scene, a second stream and a second frame buffer, renders alternating —
+        # what a caller who double-buffers an animation gets (the tail of one launch overlaps the next one; a handle serialises its own
+        # frames).  Information only: `value` stays the one-frame-at-a-time rate.
+        scene2, _, _ = load_workload(name)
+        handle2 = scene2.device_handle()
+        out2 = torch.empty_like(out)
+        s2 = torch.cuda.Stream()
+        def render2():
+            abi.check(lib.nrays_render_device(handle2, C.byref(p), C.c_void_p(out2.data_ptr()), C.c_void_p(s2.cuda_stream)))
+        for _ in range(settle + 4):
+            render_on(handle, p); render2()
+        torch.cuda.synchronize()
+        frames = max(20, min(steps, 200)) // 2 * 2
+        t0 = time.perf_counter()
+        for k in range(frames // 2):
+            render_on(handle, p); render2()
+        torch.cuda.synchronize()
+        res["two_frames_in_flight_ms_per_frame"] = round((time.perf_counter() - t0) / frames * 1e3, 5)
+        res["two_frames_in_flight_identical"] = bool(torch.equal(out, out2))
+        del scene2
     pmc_res, src = (None, None) if (args.no_pmc or not pmc) else pmc_for(name, W, H, live=not args.replay_pmc)
     res["roofline"] = roofline_block(pk, tst, W, H, lib.nrays_scene_device_bytes(handle), pmc_res, src, tile_costs)
     if not args.no_cpu_baseline:
@@ -370,6 +392,8 @@ def run_single(args):
         "scene_build_s": m["scene_build_s"], "cold_frame_ms": m["cold_frame_ms"], "second_frame_ms": m["second_frame_ms"],
         "third_frame_ms": m["third_frame_ms"], "cold_frame_note": m["cold_frame_note"],
         "moving_camera_ms_per_frame": m.get("moving_camera_ms_per_frame"),
+        "two_frames_in_flight_ms_per_frame": m.get("two_frames_in_flight_ms_per_frame"),
+        "two_frames_in_flight_identical": m.get("two_frames_in_flight_identical"),
         "roofline": m["roofline"],
     }
     if "cpu_baseline" in m:
