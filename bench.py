@@ -331,6 +331,7 @@ def main():
                     help="balls = BASELINE config 2 (the metric's workload); config4 = crytek_sponza stand-in 3840x2160 with 8 lights")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary blocks (sponza / hairball stand-ins; config 4 at N > 1)")
+    ap.add_argument("--steady-only", action="store_true", help="no moving-camera / two-frames-in-flight extras (for a rocprofv3 --stats run whose per-kernel averages should be the steady-state launches)")
     ap.add_argument("--no-pmc", action="store_true", help="no hardware counters at all (traffic: null)")
     ap.add_argument("--replay-pmc", action="store_true", help="take the counters from profiles/ instead of running rocprofv3")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall-time cap of each CPU-baseline leg")
@@ -379,7 +380,7 @@ METRIC = "Mrays/s (primary+shadow+reflection), 1920x1080, 4 bounces"
 
 def run_single(args):
     W, H = args.width, args.height
-    m = single_gpu_measure(args.scene, W, H, args.steps, args.warmup, args)
+    m = single_gpu_measure(args.scene, W, H, args.steps, args.warmup, args, moving=not args.steady_only)
     result = {
         "metric": METRIC,
         "value": m["value"], "unit": "Mrays/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,

@@ -4,7 +4,7 @@ cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/final
 timeout 900 python bench.py > gpurun_out/final/r03_bench_final.json 2> gpurun_out/final/bench.err; tail -c 400 gpurun_out/final/bench.err
 cd /tmp; export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp -o b -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-pmc > /tmp/rp_bench.json 2>/tmp/rp.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp -o b -- python $GRAFT_REPO_ROOT/bench.py --steps 400 --warmup 10 --no-cpu-baseline --no-pmc --no-secondary --steady-only > /tmp/rp_bench.json 2>/tmp/rp.err
 cp $(find /tmp/rp -name "*kernel_stats.csv" | head -1) $GRAFT_REPO_ROOT/gpurun_out/final/r03_rocprofv3_kernel_stats_bench.csv
 cd $GRAFT_REPO_ROOT
 for s in balls sponza hairball; do timeout 500 python tools/pmc_collect.py $s gpurun_out/final/r03_pmc_$s.json > /dev/null 2>&1; done
