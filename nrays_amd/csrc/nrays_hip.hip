@@ -31,6 +31,9 @@
 #include "scene_build.h"
 #include "trace_device.h"
 
+#ifndef NR_STATIC_FIRST
+#define NR_STATIC_FIRST 1 // mesh kernels: a wave's first work-list entry is assigned statically (no atomic storm at the start of a launch)
+#endif
 #ifndef NR_NT_STORES
 #define NR_NT_STORES 1 // frame-buffer stores carry the non-temporal hint: the 25 MB of a 1080p frame do not sweep the scene out of the L2s
 #endif
@@ -282,7 +285,13 @@ __global__ void __launch_bounds__(kBlock, OCC ? OCC : waves_per_simd(FEAT)) k_pr
     const uint32_t g = grab ? grab : 1u;
     const uint32_t per = (((nwt + 7u) / 8u) + g - 1u) / g * g; // wave tiles per XCD range
     const bool prefetch = grab > 1u;
-    uint32_t pending = grab ? issue_grab(work_counters, victim, grab) : 0u;
+    // The FIRST entry of a wave comes without an atomic: 2048 - 4096 waves incrementing eight counters at the start of the launch
+    // retire one every ~100 ns per counter — the last wave of an XCD reached its first tile after 25 us (sponza) / 51 us (hairball).
+    // Workgroup b statically owns entry (b / 8) * 4 + wave of list b mod 8 (dispatch deals the workgroups round-robin to the XCDs, so
+    // that is the list of its own XCD; nothing depends on it); the counters then count from the number of static owners of a list.
+    auto static_owners = [&](uint32_t x) -> uint32_t { return grab == 1u ? (uint32_t)(kBlock / 64) * ((gridDim.x + 7u - x) >> 3) : 0u; };
+    bool static_first = NR_STATIC_FIRST && grab == 1u;
+    uint32_t pending = (grab && !static_first) ? issue_grab(work_counters, victim, grab) : 0u;
     for (;;) {
       NR_TIC(tdq);
       uint32_t first, last;
@@ -323,7 +332,9 @@ __global__ void __launch_bounds__(kBlock, OCC ? OCC : waves_per_simd(FEAT)) k_pr
           // (longest-processing-time-first: the deep alpha / reflection chains start first, the frame ends on
           // cheap tiles).
           const bool ordered = R.tile_order != nullptr;
-          uint32_t k = (uint32_t)__builtin_amdgcn_readfirstlane((int)pending);
+          uint32_t k;
+          if (static_first) { victim = blockIdx.x & 7u; k = (blockIdx.x >> 3) * (uint32_t)(kBlock / 64) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+          else k = (uint32_t)__builtin_amdgcn_readfirstlane((int)pending) + (NR_STATIC_FIRST ? static_owners(victim) : 0u);
           auto list_len = [&](uint32_t x) -> uint32_t {
               if (ordered) return R.order_len ? R.order_len[x] : (nwt > x ? (nwt - x + 7u) / 8u : 0u);
               return x * per < nwt ? (nwt - x * per < per ? nwt - x * per : per) : 0u;
@@ -335,13 +346,14 @@ __global__ void __launch_bounds__(kBlock, OCC ? OCC : waves_per_simd(FEAT)) k_pr
                   victim = (victim + 1u) & 7u;
                   len = list_len(victim);
                   if (len == 0u) continue;
-                  k = (uint32_t)__builtin_amdgcn_readfirstlane((int)issue_grab(work_counters, victim, grab));
+                  k = (uint32_t)__builtin_amdgcn_readfirstlane((int)issue_grab(work_counters, victim, grab)) + (NR_STATIC_FIRST ? static_owners(victim) : 0u);
                   if (k < len) found = true;
               }
               if (!found) break; // wave-uniform
           }
           if (ordered) { first = R.tile_order[k * 8u + victim]; last = first + 1u; }
           else { first = victim * per + k; last = k + grab < len ? first + grab : victim * per + len; }
+          if (static_first) { static_first = false; victim = xcc_id(); } // from here on: this XCD's counter
           if (prefetch) pending = issue_grab(work_counters, victim, grab); // issued now, consumed after the tiles below
       }
       NR_TOC(cyc_x[0], tdq);
