@@ -41,6 +41,9 @@ for f in range(frames):
         le = np.where(had, (w[:, 1] - t0) / 100.0, np.nan)
         tail = ex - le
         last = np.argsort(ex)[::-1][:6]
+        xcc = (w[:, 3] >> 28) & 7
+        print(json.dumps({"scene": name, "frame": f, "last_work_tile_end_us_by_xcd_p10_p50_max": {int(x): [round(float(v), 0) for v in np.nanpercentile(le[xcc == x], [10, 50, 100])] for x in range(8)},
+                          "entries_per_wave_p0_50_100": [int(v) for v in np.percentile(w[:, 3] & 0xfff, [0, 50, 100])]}), flush=True)
         print(json.dumps({"scene": name, "frame": f, "span_us": round(float(ex.max()), 1), "waves_with_work": int(had.sum()),
                           "last_work_tile_end_us_p50_90_99_100": [round(float(x), 1) for x in np.nanpercentile(le, [50, 90, 99, 100])],
                           "exit_after_last_work_tile_us_p0_50_90_100": [round(float(x), 1) for x in np.nanpercentile(tail, [0, 50, 90, 100])],
