@@ -34,6 +34,9 @@
 #ifndef NR_STATIC_FIRST
 #define NR_STATIC_FIRST 1 // mesh kernels: a wave's first work-list entry is assigned statically (no atomic storm at the start of a launch)
 #endif
+#ifndef NR_PEEK_STEAL
+#define NR_PEEK_STEAL 1 // mesh kernels look at the eight work counters before they try to steal (k_primary)
+#endif
 #ifndef NR_NT_STORES
 #define NR_NT_STORES 1 // frame-buffer stores carry the non-temporal hint: the 25 MB of a 1080p frame do not sweep the scene out of the L2s
 #endif
@@ -342,10 +345,21 @@ __global__ void __launch_bounds__(kBlock, OCC ? OCC : waves_per_simd(FEAT)) k_pr
           uint32_t len = list_len(victim);
           if (k >= len) { // this XCD's list is exhausted: steal from the next non-empty one
               bool found = false;
+#if NR_PEEK_STEAL
+              // one look at all eight counters (lanes 0..7, one round trip): lists that are exhausted are not even tried — the
+              // failed atomics of the waves that run dry at the end of a frame delayed the dequeues of the waves still working
+              // (not in anti-aliased frames: millions of small tiles, the lists are image bands that run dry one after the other and
+              // most steals succeed — the look costs them 0.7 %)
+              uint32_t cnt8 = 0u;
+              if (lane < 8u && lane_log2 == 0u) cnt8 = __hip_atomic_load(&work_counters[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
               for (uint32_t tries = 0; tries < 7u && !found; ++tries) {
                   victim = (victim + 1u) & 7u;
                   len = list_len(victim);
                   if (len == 0u) continue;
+#if NR_PEEK_STEAL
+                  if ((uint32_t)__builtin_amdgcn_readlane((int)cnt8, (int)victim) + (NR_STATIC_FIRST ? static_owners(victim) : 0u) >= len) continue;
+#endif
                   k = (uint32_t)__builtin_amdgcn_readfirstlane((int)issue_grab(work_counters, victim, grab)) + (NR_STATIC_FIRST ? static_owners(victim) : 0u);
                   if (k < len) found = true;
               }
