@@ -15,14 +15,17 @@ name = sys.argv[1] if len(sys.argv) > 1 else "balls"
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 sc, cam = {"sponza": standins.sponza_scene, "hairball": standins.hairball_scene, "balls": su.balls_scene,
            "ballsfar": lambda: (su.balls_scene()[0], dict(su.balls_scene()[1], eye=(0.0, 150.0, -300.0))),
-           "primitives": lambda: su.primitives_scene(0.0, 1)}[name]()
-p, _ = su.camera_params(cam, 1920, 1080, **({"max_depth": int(sys.argv[3])} if len(sys.argv) > 3 else {}))  # optional third argument: max_depth
-out = torch.empty((1080, 1920, 3), dtype=torch.float32, device="cuda")
+           "primitives": lambda: su.primitives_scene(0.0, 1), "config4": lambda: standins.sponza_scene(n_lights=8),
+           "config5": standins.hairball_scene}[name]()
+W, H = (3840, 2160) if name in ("config4", "config5") else (1920, 1080)
+if os.environ.get("NRAYS_TIMELINE_RES"): W, H = map(int, os.environ["NRAYS_TIMELINE_RES"].split("x"))
+p, _ = su.camera_params(cam, W, H, **({"max_depth": int(sys.argv[3])} if len(sys.argv) > 3 else {}), **(dict(spp=64, window=1.0, seed=1) if name == "config5" else {}))  # optional third argument: max_depth
+out = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
 lib.nrays_debug_wave_times.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
 for f in range(frames):
     abi.check(lib.nrays_render_device(sc.device_handle(), C.byref(p), C.c_void_p(out.data_ptr()), None))
-    buf = np.zeros((8192, 4), np.uint32); n = C.c_uint32()
-    abi.check(lib.nrays_debug_wave_times(sc.device_handle(), buf.ctypes.data, 8192, C.byref(n)))
+    buf = np.zeros((16384, 4), np.uint32); n = C.c_uint32()
+    abi.check(lib.nrays_debug_wave_times(sc.device_handle(), buf.ctypes.data, 16384, C.byref(n)))
     w = buf[:n.value].astype(np.int64)
     w = w[w[:, 2] != 0]
     if os.environ.get("NRAYS_DEBUG_WAVE_WORK") == "4":  # w[:, 1] = 10 ns ticks inside fill_row (20 bits) | row entries << 20
