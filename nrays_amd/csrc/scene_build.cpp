@@ -394,7 +394,16 @@ int append_blas(const NraysSceneDesc* d, const std::vector<uint32_t>& node_ids, 
     if (out.tris.size() + pb.size() >= (1u << 28)) { err = "too many triangles"; return NRAYS_ERR_UNSUPPORTED; }
     rebase_bvh(bvh, (int32_t)out.nodes.size(), (uint32_t)out.tris.size());
     out.max_bvh_depth = std::max(out.max_bvh_depth, bvh.max_depth);
-    for (uint32_t k : bvh.order) { out.tris.push_back(recs[ref_tri[k]]); out.triuvs.push_back(uvs[ref_tri[k]]); }
+    {   // leaf-ordered copies of the triangle records and their uvs, by several threads (15 M references for the hairball)
+        const size_t base = out.tris.size(), n = bvh.order.size();
+        out.tris.resize(base + n); out.triuvs.resize(base + n);
+        const size_t tasks = n >= 400000 ? std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), 32) : 1;
+        auto gather = [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) { const uint32_t t = ref_tri[bvh.order[i]]; out.tris[base + i] = recs[t]; out.triuvs[base + i] = uvs[t]; } };
+        std::vector<std::future<void>> futs;
+        for (size_t t = 1; t < tasks; ++t) futs.push_back(std::async(std::launch::async, gather, n * t / tasks, n * (t + 1) / tasks));
+        gather(0, n / tasks);
+        for (auto& f : futs) f.get();
+    }
     out.nodes.insert(out.nodes.end(), bvh.nodes.begin(), bvh.nodes.end());
     blas.root = bvh.root;
     blas.hairy = hairy;
