@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <climits>
 #include <cmath>
 #include <cstdio>
@@ -1288,9 +1289,11 @@ int nrays_scene_create(const NraysSceneDesc* desc, NraysScene** out_scene) {
     auto bail = [&](int rc) { nrays_scene_destroy(sc); return rc; };
     if (hipGetDevice(&sc->device) != hipSuccess) return bail(fail(NRAYS_ERR_HIP, "hipGetDevice failed"));
     std::string err;
+    const auto t_create0 = std::chrono::steady_clock::now();
     int rc = build_host_scene(desc, sc->host, err);
     if (rc != NRAYS_OK) return bail(fail(rc, err));
     HostScene& h = sc->host;
+    const auto t_create1 = std::chrono::steady_clock::now();
     std::memset(&sc->d, 0, sizeof sc->d);
     if ((rc = upload(sc, h.nodes, &sc->d.nodes)) != NRAYS_OK) return bail(rc);
     if ((rc = upload(sc, h.tris, &sc->d.tris)) != NRAYS_OK) return bail(rc);
@@ -1320,6 +1323,9 @@ int nrays_scene_create(const NraysSceneDesc* desc, NraysScene** out_scene) {
         if (h.shade_alpha_tex[i] >= 0) h.shade[i].alpha_tex.texels = trecs[h.shade_alpha_tex[i]].texels;
     }
     if ((rc = upload(sc, h.shade, &sc->d.shade)) != NRAYS_OK) return bail(rc);
+    if (getenv("NRAYS_BUILD_TIMES") && h.tris.size() > 1000000)
+        fprintf(stderr, "  nrays_scene_create: build_host_scene %.2f s, uploads %.2f s\n", std::chrono::duration<double>(t_create1 - t_create0).count(),
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t_create1).count());
     sc->d.closest_root = h.closest_root; sc->d.shadow_root = h.shadow_root;
     sc->d.num_planes = (uint32_t)h.planes.size(); sc->d.num_lights = (uint32_t)h.lights.size();
     for (int a = 0; a < 3; ++a) sc->d.background[a] = h.background[a];

@@ -340,6 +340,7 @@ static bool presplit(const std::vector<TriRec>& recs, std::vector<PrimBounds>& r
 
 // Appends a BLAS over the triangles of `node_ids` (TriMesh nodes sharing one isometry).
 int append_blas(const NraysSceneDesc* d, const std::vector<uint32_t>& node_ids, HostScene& out, Blas& blas, std::string& err) {
+    const auto TA = std::chrono::steady_clock::now();
     std::vector<PrimBounds> pb;
     std::vector<TriRec> recs;
     std::vector<TriUv> uvs;
@@ -390,6 +391,7 @@ int append_blas(const NraysSceneDesc* d, const std::vector<uint32_t>& node_ids, 
     // architectural stand-in is 4 % slower with this value, profiles/r02_nodeloop_ab.log)
     BuiltBvh bvh = build_bvh(pb, NR_MAX_LEAF, hairy ? NR_PRIM_COST_HAIRY : 0.0f);
     auto T2 = std::chrono::steady_clock::now();
+    if (getenv("NRAYS_BUILD_TIMES") && recs.size() > 1000000) fprintf(stderr, "  append_blas: triangle records %.2f s\n", std::chrono::duration<double>(T0 - TA).count());
     if (getenv("NRAYS_BUILD_TIMES")) fprintf(stderr, "presplit %.2f s, build_bvh %.2f s (%zu triangles, %zu refs%s)\n", std::chrono::duration<double>(T1 - T0).count(), std::chrono::duration<double>(T2 - T1).count(), recs.size(), pb.size(), hairy ? ", hair-like" : "");
     if (out.tris.size() + pb.size() >= (1u << 28)) { err = "too many triangles"; return NRAYS_ERR_UNSUPPORTED; }
     rebase_bvh(bvh, (int32_t)out.nodes.size(), (uint32_t)out.tris.size());
@@ -407,6 +409,7 @@ int append_blas(const NraysSceneDesc* d, const std::vector<uint32_t>& node_ids, 
     out.nodes.insert(out.nodes.end(), bvh.nodes.begin(), bvh.nodes.end());
     blas.root = bvh.root;
     blas.hairy = hairy;
+    if (getenv("NRAYS_BUILD_TIMES") && recs.size() > 1000000) fprintf(stderr, "  append_blas: after the build (rebase, gather, node copy) %.2f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - T2).count());
     return NRAYS_OK;
 }
 
