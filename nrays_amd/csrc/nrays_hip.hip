@@ -1412,6 +1412,20 @@ int nrays_scene_create(const NraysSceneDesc* desc, NraysScene** out_scene) {
         if (hipEventCreate(&sc->ev_begin[k]) != hipSuccess || hipEventCreate(&sc->ev_pbegin[k]) != hipSuccess ||
             hipEventCreate(&sc->ev_pend[k]) != hipSuccess || hipEventCreate(&sc->ev_end[k]) != hipSuccess)
             return bail(fail(NRAYS_ERR_HIP, "event creation failed"));
+    {   // What a first frame would allocate, sized for frames up to 4K (larger ones re-allocate as before): the reference's caller
+        // renders a camera ONCE (loader3d.rs:67-93), so the first frame of a handle is the one that counts for it.
+        const char* e = getenv("NRAYS_PREALLOC"); // =0: allocate on the first frame (A/B switch)
+        if (!(e && atoi(e) == 0)) {
+            const size_t tab = 4 * (size_t)(3840 + 2160);
+            if (hipMalloc((void**)&sc->d_tables, tab * sizeof(double)) == hipSuccess) sc->tables_doubles = tab; else { sc->d_tables = nullptr; (void)hipGetLastError(); }
+            const uint32_t nwt = (3840u / 16u) * (2160u / 16u) * 4u;
+            if (hipMalloc((void**)&sc->d_tile_cost, (size_t)nwt * sizeof(uint32_t)) == hipSuccess &&
+                hipMalloc((void**)&sc->d_tile_order, ((size_t)nwt << sc->light_lsl) * sizeof(uint32_t)) == hipSuccess) sc->tile_slots = nwt;
+            else { if (sc->d_tile_cost) (void)hipFree(sc->d_tile_cost); sc->d_tile_cost = nullptr; sc->d_tile_order = nullptr; (void)hipGetLastError(); }
+            if (sc->light_lsl && hipMalloc((void**)&sc->d_order_len, 8 * sizeof(uint32_t)) != hipSuccess) { sc->d_order_len = nullptr; (void)hipGetLastError(); }
+            if (sc->spill_entries && hipMalloc((void**)&sc->d_spill, (size_t)kMaxGrid * kBlock * sc->spill_entries * sizeof(uint32_t)) != hipSuccess) { sc->d_spill = nullptr; (void)hipGetLastError(); }
+        }
+    }
     *out_scene = sc;
     return NRAYS_OK;
 }

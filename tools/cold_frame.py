@@ -10,7 +10,7 @@ lib = abi.load_hip_lib()
 for name in sys.argv[1:] or ["sponza"]:
     mk = {"sponza": standins.sponza_scene, "sponza8": lambda: standins.sponza_scene(n_lights=8), "hairball": standins.hairball_scene, "balls": su.balls_scene}[name]
     t = [[], [], []]
-    for rep in range(4):
+    for rep in range(9):
         sc, cam = mk()
         p, _ = su.camera_params(cam, 1920, 1080)
         out = torch.empty((1080, 1920, 3), dtype=torch.float32, device="cuda")
