@@ -15,7 +15,7 @@ name = sys.argv[1] if len(sys.argv) > 1 else "balls"
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 sc, cam = {"sponza": standins.sponza_scene, "hairball": standins.hairball_scene, "balls": su.balls_scene,
            "ballsfar": lambda: (su.balls_scene()[0], dict(su.balls_scene()[1], eye=(0.0, 150.0, -300.0))),
-           "primitives": lambda: su.primitives_scene(0.0, 1), "config4": lambda: standins.sponza_scene(n_lights=8),
+           "primitives": lambda: su.primitives_scene(0.0, 1), "config4": lambda: standins.sponza_scene(n_lights=8), "sponza8": lambda: standins.sponza_scene(n_lights=8),
            "config5": standins.hairball_scene}[name]()
 W, H = (3840, 2160) if name in ("config4", "config5") else (1920, 1080)
 if os.environ.get("NRAYS_TIMELINE_RES"): W, H = map(int, os.environ["NRAYS_TIMELINE_RES"].split("x"))
