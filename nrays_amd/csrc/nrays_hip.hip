@@ -885,6 +885,12 @@ static int ensure_queue(NraysScene* sc, uint32_t capacity) {
     return NRAYS_OK;
 }
 
+// Words of the cost-ordered work list (k_tile_order): entry k of XCD list x lives at order[8 k + x], and a list holds the wave
+// tiles i = x (mod 8) — up to ceil(nwt / 8) of them — each as up to 2^lsl light-parallel parts.  The array therefore needs
+// 8 * ceil(nwt / 8) << lsl words, not nwt << lsl: with nwt = 4 (mod 8) and every tile of one of the lists 0..3 split, the last
+// entries of that list lie up to (4 << lsl) - 4 words beyond nwt << lsl.
+static size_t order_slots(uint32_t nwt, uint32_t lsl) { return ((((size_t)nwt + 7u) / 8u) * 8u) << lsl; }
+
 static uint32_t tile_rows(const NraysRenderParams* p) {
     if (p->band_rows == 0 || p->band_owners <= 1) return p->height;
     uint32_t nb = (p->height + p->band_rows - 1) / p->band_rows;
@@ -1100,7 +1106,7 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
             if (sc->d_tile_order) { (void)hipFree(sc->d_tile_order); sc->d_tile_order = nullptr; }
             sc->tile_slots = 0; sc->cost_valid = false; sc->order_valid = false;
             HIP_TRY(hipMalloc((void**)&sc->d_tile_cost, (size_t)nwt * sizeof(uint32_t)));
-            HIP_TRY(hipMalloc((void**)&sc->d_tile_order, ((size_t)nwt << sc->light_lsl) * sizeof(uint32_t)));
+            HIP_TRY(hipMalloc((void**)&sc->d_tile_order, order_slots(nwt, sc->light_lsl) * sizeof(uint32_t)));
             sc->tile_slots = nwt;
         }
         if (split_lsl && !sc->d_order_len) HIP_TRY(hipMalloc((void**)&sc->d_order_len, 8 * sizeof(uint32_t)));
@@ -1420,7 +1426,7 @@ int nrays_scene_create(const NraysSceneDesc* desc, NraysScene** out_scene) {
             if (hipMalloc((void**)&sc->d_tables, tab * sizeof(double)) == hipSuccess) sc->tables_doubles = tab; else { sc->d_tables = nullptr; (void)hipGetLastError(); }
             const uint32_t nwt = (3840u / 16u) * (2160u / 16u) * 4u;
             if (hipMalloc((void**)&sc->d_tile_cost, (size_t)nwt * sizeof(uint32_t)) == hipSuccess &&
-                hipMalloc((void**)&sc->d_tile_order, ((size_t)nwt << sc->light_lsl) * sizeof(uint32_t)) == hipSuccess) sc->tile_slots = nwt;
+                hipMalloc((void**)&sc->d_tile_order, order_slots(nwt, sc->light_lsl) * sizeof(uint32_t)) == hipSuccess) sc->tile_slots = nwt;
             else { if (sc->d_tile_cost) (void)hipFree(sc->d_tile_cost); sc->d_tile_cost = nullptr; sc->d_tile_order = nullptr; (void)hipGetLastError(); }
             if (sc->light_lsl && hipMalloc((void**)&sc->d_order_len, 8 * sizeof(uint32_t)) != hipSuccess) { sc->d_order_len = nullptr; (void)hipGetLastError(); }
             if (sc->spill_entries && hipMalloc((void**)&sc->d_spill, (size_t)kMaxGrid * kBlock * sc->spill_entries * sizeof(uint32_t)) != hipSuccess) { sc->d_spill = nullptr; (void)hipGetLastError(); }

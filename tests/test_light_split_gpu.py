@@ -72,3 +72,25 @@ def test_split_tiles_with_area_lights_bands_and_ragged_frames(gpu, monkeypatch):
             abi.check(lib.nrays_render(sc.device_handle(), C.byref(tp), tile.ctypes.data_as(C.POINTER(C.c_float))))
         own = tiling.owned_rows(67, 16, owner, 3)
         assert np.array_equal(tile[:len(own)], ref[0][0][own])
+
+
+def test_every_tile_split_without_the_preallocated_order_buffer(gpu, monkeypatch):
+    """101 x 67 pixels = 140 wave tiles = 4 (mod 8): with every tile split, the lists 0..3 hold one tile more than the lists 4..7 and
+    their last entries lie beyond `tiles << k` words (the order buffer must hold 8 ceil(tiles / 8) << k).  The 4K
+    preallocation of a handle hides the difference, so the handles of this test allocate on their first frame (NRAYS_PREALLOC=0);
+    several handles in a row, so that an out-of-bounds write would land in a neighbouring allocation that is in use."""
+    def make():
+        sc, cam = su.mesh_scene(n_lights=2)
+        sc._lights = list(sc._lights) * 4  # 8 lights: 8 parts per tile
+        sc._descriptor = None
+        return sc, cam
+    monkeypatch.setenv("NRAYS_PREALLOC", "0")
+    monkeypatch.setenv("NRAYS_LIGHT_SPLIT", "0")
+    _, _, ref = _frames(make, 101, 67, 1)
+    monkeypatch.setenv("NRAYS_LIGHT_SPLIT", "-1")
+    keep = []
+    for _ in range(3):
+        sc, _, got = _frames(make, 101, 67, 3)
+        keep.append(sc)
+        for img, rays in got:
+            assert rays == ref[0][1] and np.array_equal(img, ref[0][0])
