@@ -242,4 +242,17 @@ struct DRender {
 };
 constexpr uint32_t kEntrySplit = 0x80000000u, kEntryTileMask = 0x0fffffffu;
 
+// Kernel permutations by scene content (decided once per scene on the host): a scene only pays, in
+// registers and instructions, for the code paths it can reach.
+enum Features : int {
+    kFeatAnalytic = 1,     // balls / cuboids / cylinders / capsules / cones / planes exist
+    kFeatMesh = 2,         // TriMesh nodes exist (BLAS traversal, ray/triangle)
+    kFeatAlphaShadow = 4,  // some node may be non-opaque to shadow rays (per-node closest hit + colour filter)
+    kFeatDouble = 8,       // some node can spawn a reflection AND a refraction at one hit (second child -> HBM queue)
+    kFeatMultiSample = 16, // more than one light sample per hit: shadow rays are traced inside the light loop;
+                           // otherwise the single shadow ray is traced before the shading state exists
+    kFeatAll = 31,
+    kFeatLdsScene = 32     // analytic-only scenes whose records fit DScene::lds_blob: the kernel reads them from LDS
+};
+
 } // namespace nrays

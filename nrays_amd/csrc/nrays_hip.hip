@@ -30,7 +30,10 @@
 #include "../../include/nrays_abi.h"
 #include "device_types.h"
 #include "scene_build.h"
+#include "scene_handle.h"
+#include "tile_device.h"
 #include "trace_device.h"
+#include "wavefront.h"
 
 #ifndef NR_STATIC_FIRST
 #define NR_STATIC_FIRST 1 // mesh kernels: a wave's first work-list entry is assigned statically (no atomic storm at the start of a launch)
@@ -47,8 +50,6 @@ namespace nrays {
 #define NRAYS_WAVES_PER_SIMD 2 // second __launch_bounds__ argument: caps the VGPR budget at 512 / this
 #endif
 constexpr int kTile = 16;          // four consecutive 8x8 wave tiles form a 16x16 pixel block
-constexpr int kNumCounts = kMaxGenerations + 2 + 8; // queue round counters + 8 per-XCD work counters
-constexpr int kMaxGrid = 2048;     // upper bound of the persistent grid (the launch uses CUs x waves/SIMD workgroups)
 
 // XCD-aware dynamic scheduling of the persistent grid (scenes with meshes; analytic-only scenes use per-workgroup
 // lists through an LDS counter, see k_primary).  Every XCD owns a work list with its own counter in HBM: without
@@ -134,58 +135,6 @@ __device__ __forceinline__ void flush_counters(DeviceCounters* ctr, const Cnt& c
 #define NR_OPAQUE_MESH_WAVES 4
 #endif
 constexpr int waves_per_simd(int feat) { return (feat & ~(kFeatMultiSample | kFeatLdsScene)) == kFeatMesh ? (NRAYS_WAVES_PER_SIMD > NR_OPAQUE_MESH_WAVES ? NRAYS_WAVES_PER_SIMD : NR_OPAQUE_MESH_WAVES) : NRAYS_WAVES_PER_SIMD; }
-
-// One row of the compact frame buffer outside the window of blocks that can see the scene (k_primary): background sums
-// (padding rows of the last band: zero) for the floats t0, t0 + tstep, ... of the row.  Out of line: its registers and
-// uniforms stay out of the tile loop's allocation.
-// INL: the copy inside the tile loop of the workgroup-list kernels is inlined — a call returns through `s_waitcnt vmcnt(0)`, i.e. waits
-// for the row's stores to be acknowledged (1.3 us per quarter row, 6 us at the end of a frame: 20 us of the 45 us balls launch were
-// workgroups finishing their rows one acknowledged call after the other).
-__device__ __attribute__((always_inline)) inline void fill_background_row_body(float bg0, float bg1, float bg2, uint32_t spp, float* out, uint32_t width, uint32_t height,
-                                                 uint32_t band_rows, uint32_t band_owner, uint32_t band_owners, uint32_t win_x0, uint32_t win_nx,
-                                                 uint32_t win_y0, uint32_t win_ny, uint32_t lane_log2, uint32_t rl, uint32_t t0, uint32_t tstep) {
-    const uint32_t bwl = lane_log2 ? (7u - lane_log2) >> 1 : 4u, bhl = lane_log2 ? (6u - lane_log2) >> 1 : 4u;
-    const uint32_t wi0 = win_x0 << bwl, wi1 = (win_x0 + win_nx) << bwl, wr0 = win_y0 << bhl, wr1 = (win_y0 + win_ny) << bhl;
-    float b0 = 0.0f, b1 = 0.0f, b2 = 0.0f;
-    for (uint32_t s = 0; s < spp; ++s) { b0 = b0 + bg0; b1 = b1 + bg1; b2 = b2 + bg2; }
-    uint32_t j = rl;
-    if (band_rows != 0 && band_owners > 1) j = ((rl / band_rows) * band_owners + band_owner) * band_rows + (rl % band_rows);
-    const bool real = j < height;
-    const bool split = rl >= wr0 && rl < wr1 && win_nx != 0u; // this row crosses the window: skip its columns
-    __attribute__((address_space(1))) float* row = (__attribute__((address_space(1))) float*)(out + (size_t)rl * width * 3);
-    if (!real) { b0 = 0.0f; b1 = 0.0f; b2 = 0.0f; }
-    if (((width * 3u) & 3u) == 0u && (((uintptr_t)out) & 15u) == 0u && (tstep % 3u) == 1u) {
-        // 16-byte stores: chunk q holds the floats 4q .. 4q + 3, i.e. the channels (q mod 3), (q + 1) mod 3, ... — three patterns, and
-        // q mod 3 advances by one per step because tstep = 1 (mod 3).  (The scalar loop below spent a division and a 4-byte store per
-        // float: ~1.5 us per call, and the rows of a workgroup whose waves sit on long tiles were the tail of the balls frame.)
-        typedef float f4v __attribute__((ext_vector_type(4)));
-        const f4v pat[3] = {f4v{b0, b1, b2, b0}, f4v{b1, b2, b0, b1}, f4v{b2, b0, b1, b2}};
-        const uint32_t nq = width * 3u / 4u, f_lo = 3u * wi0, f_hi = 3u * wi1; // floats [f_lo, f_hi) belong to the window
-        uint32_t ph = t0 % 3u;
-        for (uint32_t q = t0; q < nq; q += tstep, ph = ph == 2u ? 0u : ph + 1u) {
-            const uint32_t f = 4u * q;
-            const f4v v = ph == 0u ? pat[0] : (ph == 1u ? pat[1] : pat[2]);
-#if NR_NT_STORES
-            if (!split || f + 4u <= f_lo || f >= f_hi) { __builtin_nontemporal_store(v, (__attribute__((address_space(1))) f4v*)(row + f)); continue; }
-#else
-            if (!split || f + 4u <= f_lo || f >= f_hi) { *(__attribute__((address_space(1))) f4v*)(row + f) = v; continue; }
-#endif
-            for (uint32_t k = 0; k < 4u; ++k) if (f + k < f_lo || f + k >= f_hi) row[f + k] = v[k]; // a chunk across the window's edge
-        }
-        return;
-    }
-    for (uint32_t f = t0; f < width * 3u; f += tstep) {
-        const uint32_t i = f / 3u, c = f - i * 3u;
-        if (split && i >= wi0 && i < wi1) continue;
-        row[f] = c == 0u ? b0 : (c == 1u ? b1 : b2);
-    }
-}
-
-__device__ __noinline__ void fill_background_row(float bg0, float bg1, float bg2, uint32_t spp, float* out, uint32_t width, uint32_t height,
-                                                 uint32_t band_rows, uint32_t band_owner, uint32_t band_owners, uint32_t win_x0, uint32_t win_nx,
-                                                 uint32_t win_y0, uint32_t win_ny, uint32_t lane_log2, uint32_t rl, uint32_t t0, uint32_t tstep) {
-    fill_background_row_body(bg0, bg1, bg2, spp, out, width, height, band_rows, band_owner, band_owners, win_x0, win_nx, win_y0, win_ny, lane_log2, rl, t0, tstep);
-}
 
 // OCC != 0: the alpha-shadow mesh permutations also exist at three waves per SIMD (168 VGPRs, ~64 dwords of scratch per lane): a
 // wave then runs slower, which lengthens a frame that is as long as its longest tile (sponza 1080p: 1.40 -> 1.67 ms) and shortens a
@@ -757,94 +706,9 @@ int set_last_error(int status, const std::string& msg) { return fail(status, msg
                         std::string(#expr) + ": " + hipGetErrorString(e_));                               \
     } while (0)
 
-struct QueueMem {
-    RayQueue q;
-    void* block = nullptr;
-};
-
 } // namespace nrays
 
 using namespace nrays;
-
-struct NraysScene {
-    int device = 0;
-    HostScene host;          // kept for counts only; bulk arrays are released after upload
-    DScene d;
-    std::vector<void*> allocs;
-    uint64_t scene_bytes = 0; // device bytes of the uploaded scene arrays (BVH nodes, triangles, records, textures)
-    // per-scene transient state, grown on demand
-    QueueMem queue[2];
-    uint32_t queue_capacity = 0;
-    uint32_t* d_counts_set[2] = {nullptr, nullptr};         // double-buffered, kNumCounts each
-    DeviceCounters* d_counters_set[2] = {nullptr, nullptr}; // double-buffered per frame
-    uint32_t* d_counts = nullptr;         // set used by the last launch
-    DeviceCounters* d_counters = nullptr; // set used by the last frame
-    uint64_t launch_index = 0, frame_index = 0;
-    uint32_t* d_spill = nullptr;
-    long long* d_fixed = nullptr; size_t fixed_slots = 0; // per-pixel fixed-point sums of the queued chains (double-branching scenes)
-    double* d_tables = nullptr; size_t tables_doubles = 0; // raygen tables: 4 * (width + height) f64
-    uint32_t tab_w = 0, tab_h = 0; double tab_m[16] = {0}; bool tab_valid = false;
-    // previous frame's wave-tile costs (k_primary) and the order derived from them (k_tile_order); valid for one
-    // (width, rows, band) geometry at a time
-    uint32_t* d_tile_cost = nullptr; uint32_t* d_tile_order = nullptr; uint32_t tile_slots = 0;
-    // light-parallel tiles: log2 of the lanes per pixel (0 = the scene is not eligible), the split threshold in units of the frame's
-    // work per resident wave (NRAYS_LIGHT_SPLIT: 0 = never, < 0 = every tile, default 1), the lengths of the eight lists
-    uint32_t light_lsl = 0; float light_split_factor = 1.0f; uint32_t* d_order_len = nullptr;
-    uint64_t cost_key = 0; bool cost_valid = false;
-    uint32_t cost_tiles = 0, cost_grid = 0; // wave tiles / workgroups of the frame that recorded d_tile_cost last (nrays_get_tile_costs)
-    // analytic scenes (workgroup lists): costs are recorded on the first frame of a camera, sorted once on the second, and
-    // the order is then reused as long as the camera stays (the scene of a handle never changes)
-    uint64_t cost_cam = 0, order_key = 0, order_cam = 0; bool order_valid = false; uint32_t order_age = 0;
-    // ... and the sort also reports the sum and the maximum of the costs: their ratio is the frame's parallelism, which
-    // decides between cost-ordered lists with the long tiles on the first workgroup of each CU (few long tiles) and image-order
-    // lists (many tiles: throughput)
-#ifdef NR_DEBUG_TILE_COSTS
-    uint32_t* d_wave_times = nullptr; uint32_t dbg_grid = 0;
-#endif
-    unsigned long long* d_cost_stats = nullptr; unsigned long long* h_cost_stats = nullptr; hipEvent_t ev_stats = nullptr;
-    bool stats_pending = false, lone_waves = false;
-    uint32_t spill_entries = 0; // HBM stack entries per lane beyond the kLdsStack entries kept in LDS (0 = never needed)
-    int num_cus = 256;
-    int features = kFeatAll;
-    float* d_frame = nullptr; size_t frame_floats = 0;
-    uint8_t* d_rgb8 = nullptr; size_t rgb8_bytes = 0; // nrays_render_rgb8
-    hipStream_t own_stream = nullptr;
-    // ring of HIP event triples (frame begin, primary kernel begin/end, frame end) recorded on the render
-    // stream; nrays_get_stats averages the frames recorded since its previous call.
-    static constexpr int kRing = 256;
-    hipEvent_t ev_begin[kRing] = {}, ev_pbegin[kRing] = {}, ev_pend[kRing] = {}, ev_end[kRing] = {};
-    bool single_launch[kRing] = {};
-    bool has_prepass[kRing] = {}; // the frame started with k_tile_order: ev_begin was recorded before it
-    uint64_t frames_recorded = 0, frames_reported = 0;
-    DeviceCounters* d_counters_primary = nullptr; // snapshot taken right after the primary kernel
-    hipStream_t last_stream = nullptr;
-    hipEvent_t last_done = nullptr; // last event recorded by the previous render (one of the ring's events)
-    hipEvent_t ev_switch = nullptr; // recorded on the previous render's stream when a render arrives on another one
-    bool have_last = false;
-    // A/B and test switches, read ONCE when the handle is created (never in the frame path)
-    uint64_t max_primary_per_launch = 32ull << 20; // NRAYS_MAX_PRIMARY: sample batching threshold (tests force several launches)
-    bool max_primary_forced = false;
-    int lane_log2_override = -1;                    // NRAYS_LANE_LOG2: cap of the lanes per pixel of AA frames (A/B)
-    // The HIP events behind NraysStats::kernel_ms_* are recorded on every 4th frame of a handle (and on every instrumented
-    // one): three event records per frame cost ~6 us of a 85 us frame (balls: 0.0849 -> 0.0789 ms per step); the averages
-    // nrays_get_stats reports are over the sampled frames.  NRAYS_EVENT_STRIDE overrides it (1 = every frame).
-    uint32_t event_stride = 4;
-    uint64_t frames_total = 0;
-    bool last_timed = true;
-    int grab_override = -1;                         // NRAYS_GRAB
-    bool lpt_enabled = true;                        // NRAYS_LPT=0 restores image order
-    bool lpt_reuse = true;                          // NRAYS_LPT_REUSE=0: mesh scenes re-sort their tiles every frame even when the camera rests
-    bool lpt_analytic = true;                       // NRAYS_LPT_ANALYTIC=0: analytic scenes never switch to cost-ordered lists
-    int grid_wg_per_cu = 0;                         // NRAYS_GRID_WG_PER_CU=n caps the persistent grid at n workgroups per CU (tuning)
-    double lone_factor = 1.5;                       // NRAYS_LONE_FACTOR: cost-ordered lead / second lists when sum / max of the tile costs < factor * SIMDs
-    int lead_per_wg = 4;                            // NRAYS_LEAD_PER_WG=1..4: long entries per lead workgroup
-    bool lead_mode = true;                          // NRAYS_LEAD_WGS=0: cost-ordered lists run on one workgroup per CU instead of lead + second workgroups
-    int occ_override = -1;                          // NRAYS_OCC=2|3: waves per SIMD of the alpha-shadow mesh kernels (A/B)
-    bool cull_enabled = true;                       // NRAYS_SCREEN_CULL=0: no wave tile is decided from the scene's screen bounds
-    NraysStats last;
-    uint64_t last_primary = 0, last_primary_first_batch = 0;
-    bool last_instrumented = false;
-};
 
 namespace nrays {
 
@@ -1067,7 +931,10 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
     const int slot = (int)(sc->frames_recorded % NraysScene::kRing);
     // events: [pbegin .. pend] brackets the first primary launch; the frame spans [pbegin .. end], and
     // `end` is only recorded separately when something follows the primary kernel
-    const bool single_launch = !instrumented && !queued && p->ray_per_pixel <= batch && p->ray_per_pixel == 1;
+    // The staged ("wavefront") form of the trace loop (wavefront.hip) renders this frame instead of k_primary when the scene is eligible and
+    // NRAYS_WAVEFRONT / the library's rule say so; pixels are identical either way.
+    const bool staged = !instrumented && wavefront_wanted(sc, p, lane_log2);
+    const bool single_launch = !staged && !instrumented && !queued && p->ray_per_pixel <= batch && p->ray_per_pixel == 1;
     sc->d_counters = sc->d_counters_set[sc->frame_index & 1];
     DeviceCounters* next_ctr = sc->d_counters_set[(sc->frame_index + 1) & 1];
     sc->frame_index++;
@@ -1094,6 +961,13 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
     // (not for the sample-major frames of anti-aliased renders: their wave tiles are a few pixels each — 8 M of them for config 5 —
     // and far more even; recording, sorting and following the order costs more than the tail it removes: hairball 4K 64 spp
     // 251 -> 222 ms without it, sponza 1080p 4 / 16 / 64 spp 2-4 %, profiles/r02_aa_lpt.log)
+    if (staged) {
+        sc->d_counts = sc->d_counts_set[sc->launch_index & 1];
+        uint32_t* next_counts = sc->d_counts_set[(sc->launch_index + 1) & 1];
+        sc->launch_index++;
+        const int rc = wavefront_render(sc, p, R, d_out, stream, tiles_x, tiles_y, timed, slot, next_ctr, next_counts);
+        if (rc != NRAYS_OK) return rc;
+    } else {
     bool lpt = grab >= 1u && lane_log2 == 0u;
     lpt = lpt && sc->lpt_enabled; // A/B switch (NRAYS_LPT=0)
     if (instrumented && sc->light_lsl) lpt = false; // the instrumented kernel does not decode the split entries a plain frame's order may hold
@@ -1253,6 +1127,7 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
             folded = true;
         }
     }
+    } // !staged
     if (p->ray_per_pixel > 1) {
         size_t n = (size_t)npix_local * 3;
         hipLaunchKernelGGL(k_resolve, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_out, n, (float)p->ray_per_pixel);
@@ -1393,6 +1268,7 @@ int nrays_scene_create(const NraysSceneDesc* desc, NraysScene** out_scene) {
       if ((f & kFeatMultiSample) && (f & kFeatMesh) && !(f & kFeatDouble) && h.lights.size() >= 2) { uint32_t l = 1; while (l < 3u && (2u << l) <= h.lights.size()) ++l; sc->light_lsl = l; } }
     if (const char* e = getenv("NRAYS_LIGHT_SPLIT")) sc->light_split_factor = (float)atof(e);
     if (const char* e = getenv("NRAYS_OCC")) sc->occ_override = atoi(e);
+    if (const char* e = getenv("NRAYS_WAVEFRONT")) sc->wavefront_mode = atoi(e);
     if (const char* e = getenv("NRAYS_LPT_ANALYTIC")) sc->lpt_analytic = atoi(e) != 0;
     if (const char* e = getenv("NRAYS_LPT_REUSE")) sc->lpt_reuse = atoi(e) != 0;
     if (const char* e = getenv("NRAYS_LEAD_WGS")) sc->lead_mode = atoi(e) != 0;
@@ -1465,6 +1341,7 @@ void nrays_scene_destroy(NraysScene* sc) {
         if (sc->ev_pend[k]) (void)hipEventDestroy(sc->ev_pend[k]);
         if (sc->ev_end[k]) (void)hipEventDestroy(sc->ev_end[k]);
     }
+    wavefront_release(sc);
     if (sc->own_stream) (void)hipStreamDestroy(sc->own_stream);
     delete sc;
 }

@@ -44,19 +44,6 @@ constexpr int32_t kParked = (int32_t)0x80000002;   // a lane that yielded its no
 #define NR_SCALAR_NODES 1 // wave-uniform node visits fetch the node with scalar loads (traverse())
 #endif
 
-// Kernel permutations by scene content (decided once per scene on the host): a scene only pays, in
-// registers and instructions, for the code paths it can reach.
-enum Features : int {
-    kFeatAnalytic = 1,     // balls / cuboids / cylinders / capsules / cones / planes exist
-    kFeatMesh = 2,         // TriMesh nodes exist (BLAS traversal, ray/triangle)
-    kFeatAlphaShadow = 4,  // some node may be non-opaque to shadow rays (per-node closest hit + colour filter)
-    kFeatDouble = 8,       // some node can spawn a reflection AND a refraction at one hit (second child -> HBM queue)
-    kFeatMultiSample = 16, // more than one light sample per hit: shadow rays are traced inside the light loop;
-                           // otherwise the single shadow ray is traced before the shading state exists
-    kFeatAll = 31,
-    kFeatLdsScene = 32     // analytic-only scenes whose records fit DScene::lds_blob: the kernel reads them from LDS
-};
-
 // ---------------------------------------------------------------- vector algebra (f64) -------
 struct d3 { double x, y, z; };
 NR_DEV d3 D3(double x, double y, double z) { d3 r; r.x = x; r.y = y; r.z = z; return r; }
