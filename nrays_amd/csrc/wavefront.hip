@@ -37,10 +37,14 @@
 #include "scene_handle.h"
 #include "tile_device.h"
 #include "trace_device.h"
+#include "stream_device.h"
 #include "wavefront.h"
 
 #ifndef NR_WF_OCC
 #define NR_WF_OCC 4 // waves per SIMD of the stage kernels (second __launch_bounds__ argument: 128 VGPRs)
+#endif
+#ifndef NR_WF_OCC_RF
+#define NR_WF_OCC_RF 3 // waves per SIMD of the stages with lane refill (their per-lane stream state costs registers)
 #endif
 #ifndef NR_WF_OCC_SHADE
 #define NR_WF_OCC_SHADE NR_WF_OCC
@@ -545,6 +549,243 @@ __global__ void k_wf_resolve(DRender R, const float* __restrict__ acc, float* __
     o[0] = tx; o[1] = ty; o[2] = tz;
 }
 
+// ================================================================================================ stages with lane refill
+// The same three traversal stages over traverse_stream() (stream_device.h): a lane whose ray is finished delivers its result and
+// takes the next ray of the wave's stream instead of idling until the slowest lane of its 64 is done.  The streams below hand out
+// the rays of the items a wave claims (WfClaim) in item order, so a wave's lanes still hold rays of neighbouring pixels.
+
+// Primary rays of the wave tiles of a pass: position r of a tile = lane slot r % 64 of round r / 64 of k_wf_primary's loops (the same
+// pixel, sample and path for the same r).  Per lane: the key and path of the ray in flight (origin and direction live in traverse_stream).
+template <int FEAT, bool PLAIN>
+struct WfPrimarySource {
+    const DScene& S; const DRender& R; const WfQueue& q; WfOut& wo; WfClaim& work; float* acc; float* out; DeviceCounters* ctr;
+    uint32_t tile_begin, lane_log2, spp, total_pos;
+    uint32_t item, pos; bool have, exhausted; // wave-uniform
+    unsigned long long key; uint32_t path;    // per lane
+    NR_DEV void init(uint32_t tile_begin_) {
+        tile_begin = tile_begin_; lane_log2 = PLAIN ? 0u : R.lane_log2; spp = PLAIN ? 1u : R.spp;
+        total_pos = ((spp + (1u << lane_log2) - 1u) >> lane_log2) * 64u;
+        item = 0u; pos = 0u; have = false; exhausted = false; key = 0ULL; path = 0u;
+    }
+    NR_DEV bool more() const { return !exhausted; }
+    NR_DEV void background(uint32_t pth) const { // Scene::trace returns the background (scene.rs:157-161): the chain's sum is 0 + background
+        float* a = acc + (size_t)pth * 3;
+        const float c0 = 0.0f + S.background[0], c1 = 0.0f + S.background[1], c2 = 0.0f + S.background[2];
+        __builtin_nontemporal_store(c0, a); __builtin_nontemporal_store(c1, a + 1); __builtin_nontemporal_store(c2, a + 2);
+    }
+    // pixel / sample / path of position r of wave tile `it` (relative to the pass); false: no sample there
+    NR_DEV bool locate(uint32_t it, uint32_t r, uint32_t& i, uint32_t& j, uint32_t& s, uint32_t& pix, uint32_t& pth, bool& pad) const {
+        const uint32_t slot = r & 63u, p = slot >> lane_log2, sq = slot & ((1u << lane_log2) - 1u);
+        s = ((r >> 6) << lane_log2) + sq;
+        uint32_t rl;
+        wf_tile_pixel(R, lane_log2, tile_begin + it, p, i, rl);
+        j = wf_global_row(R, rl);
+        const bool active = i < R.width && rl < R.rows_local && j < R.height;
+        pix = rl * R.width + i;
+        pth = spp == 1u ? pix : (it * (64u >> lane_log2) + p) * spp + s;
+        pad = !active && sq == 0u && r < 64u && i < R.width && rl < R.rows_local; // padding rows of the last band
+        return active && s < spp;
+    }
+    NR_DEV void refill(bool idle, bool& got, d3& o, d3& d, double& tlimit) {
+        const uint32_t lane = __lane_id();
+        for (int round = 0; round < 3; ++round) {
+            if (!have) {
+                if (!work.get(item)) { exhausted = true; return; }
+                have = true; pos = 0u;
+                // the tile's own lane slots: padding rows, and whether any of its pixels lies inside the scene's screen bounds
+                uint32_t i, j, s, pix, pth; bool pad;
+                locate(item, lane, i, j, s, pix, pth, pad);
+                if (pad) { float* p = out + (size_t)pix * 3; p[0] = 0.0f; p[1] = 0.0f; p[2] = 0.0f; }
+                const bool inside = i < R.width && j < R.height && (int32_t)i >= R.cull_i0 && (int32_t)i <= R.cull_i1 && (int32_t)j >= R.cull_j0 && (int32_t)j <= R.cull_j1;
+                if (__ballot(inside) == 0ULL) { // no ray of this tile can reach the scene: every sample is the background
+                    for (uint32_t r = lane; r < total_pos; r += 64u) { if (locate(item, r, i, j, s, pix, pth, pad)) background(pth); }
+                    have = false;
+                    continue;
+                }
+            }
+            const bool want = idle && !got;
+            const unsigned long long m = __ballot(want);
+            if (m == 0ULL) return;
+            const uint32_t n = (uint32_t)__popcll(m), left = total_pos - pos, take = n < left ? n : left;
+            const uint32_t rank = (uint32_t)__popcll(m & ((1ULL << lane) - 1ULL));
+            if (want && rank < take) {
+                uint32_t i, j, s, pix, pth; bool pad;
+                if (locate(item, pos + rank, i, j, s, pix, pth, pad)) {
+                    RayState ray;
+                    generate_primary<PLAIN>(R, i, j, s, pix, ray);
+                    if (primary_may_hit(S, ray.o, ray.d)) { got = true; o = ray.o; d = ray.d; key = ray.key; path = pth; }
+                    else background(pth);
+                }
+            }
+            pos += take;
+            if (pos >= total_pos) have = false;
+        }
+    }
+    NR_DEV bool deliver(bool fin, d3 o, d3 d, bool hit, const Hit& h, bool blocked, f3 filter, bool gated) {
+        (void)blocked; (void)filter;
+        bool ok = false, again = false;
+        if (fin) {
+            if (hit) {
+                Isect is; uint32_t node_id;
+                if (resolve_hit<false, FEAT, true>(S, o, d, h, is, node_id) || gated) ok = true; else again = true;
+            } else background(path);
+        }
+        const uint32_t at = wo.append(q, ok);
+        if (ok) {
+            if (at != ~0u) {
+                RayState ray; ray.o = o; ray.d = d; ray.refr = 1.0; ray.energy = 1.0f; ray.weight = 1.0f; ray.key = key; ray.pixel = path;
+                wf_store_ray(q, at, ray, path); wf_store_hit(q, at, true, h);
+            } else atomicOr(&ctr->overflow, 1u);
+        }
+        return again;
+    }
+};
+
+template <int FEAT, bool PLAIN>
+__global__ void __launch_bounds__(kBlock, NR_WF_OCC_RF) k_wf_primary_rf(DScene S, DRender R, WfQueue q, float* __restrict__ out, float* __restrict__ acc, DeviceCounters* ctr,
+                                                                     uint32_t* spill, uint32_t tiles_x, uint32_t tiles_y, uint32_t tile_begin, uint32_t tile_end,
+                                                                     uint32_t* claim_next, uint32_t* clear_next, uint32_t* zero_counts, DeviceCounters* zero_ctr) {
+    __shared__ uint32_t lds_stack[kLdsStack * kBlock];
+    if (blockIdx.x == 0) {
+        if (zero_counts && threadIdx.x < kNumCounts) zero_counts[threadIdx.x] = 0u;
+        if (zero_ctr && threadIdx.x < sizeof(DeviceCounters) / 4) ((uint32_t*)zero_ctr)[threadIdx.x] = 0u;
+    }
+    wf_clear_next(clear_next, kWfMaxSegs);
+    Stack st; WfStackInit::make(st, lds_stack, spill);
+    Cnt cnt; wf_cnt_init(cnt);
+    const uint32_t lane_log2 = PLAIN ? 0u : R.lane_log2;
+    const bool fill_rows = (R.win_nx < tiles_x || R.win_ny < tiles_y) && tile_begin == 0u;
+    if (fill_rows)
+        for (uint32_t rl = blockIdx.x; rl < R.rows_local; rl += gridDim.x)
+            fill_background_row(S.background[0], S.background[1], S.background[2], R.spp, out, R.width, R.height, R.band_rows, R.band_owner, R.band_owners,
+                                R.win_x0, R.win_nx, R.win_y0, R.win_ny, lane_log2, rl, threadIdx.x, kBlock);
+    const uint32_t total_waves = gridDim.x * (kBlock / 64);
+    const uint32_t my_wave = blockIdx.x * (kBlock / 64) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    WfOut wo; wo.init();
+    WfClaim work; work.init(claim_next, tile_end - tile_begin, my_wave, total_waves);
+    WfPrimarySource<FEAT, PLAIN> src{S, R, q, wo, work, acc, out, ctr};
+    src.init(tile_begin);
+    traverse_stream<false, FEAT>(S, st, src, cnt);
+    wo.finish(q);
+    wf_flush(ctr, cnt);
+}
+
+// The rays of a queue for their closest hit (generations >= 1).
+template <int FEAT>
+struct WfClosestSource {
+    const DScene& S; const WfQueue& q; WfClaim& work;
+    uint32_t chunk, pos, nvalid; bool have, exhausted; // wave-uniform
+    uint32_t at;                                        // per lane
+    NR_DEV void init() { chunk = 0u; pos = 0u; nvalid = 0u; have = false; exhausted = false; at = 0u; }
+    NR_DEV bool more() const { return !exhausted; }
+    NR_DEV void refill(bool idle, bool& got, d3& o, d3& d, double& tlimit) {
+        const uint32_t lane = __lane_id();
+        for (int round = 0; round < 3; ++round) {
+            if (!have) {
+                if (!work.get(chunk)) { exhausted = true; return; }
+                nvalid = wf_chunk_valid(q, chunk); pos = 0u; have = nvalid != 0u;
+                if (!have) continue;
+            }
+            const bool want = idle && !got;
+            const unsigned long long m = __ballot(want);
+            if (m == 0ULL) return;
+            const uint32_t n = (uint32_t)__popcll(m), left = nvalid - pos, take = n < left ? n : left;
+            const uint32_t rank = (uint32_t)__popcll(m & ((1ULL << lane) - 1ULL));
+            if (want && rank < take) { at = chunk * 64u + pos + rank; wf_load_od(q, at, o, d); got = true; }
+            pos += take;
+            if (pos >= nvalid) have = false;
+        }
+    }
+    NR_DEV bool deliver(bool fin, d3 o, d3 d, bool hit, const Hit& h, bool blocked, f3 filter, bool gated) {
+        (void)blocked; (void)filter;
+        bool again = false;
+        if (fin) {
+            bool ok = false;
+            if (hit) { Isect is; uint32_t node_id; if (resolve_hit<false, FEAT, true>(S, o, d, h, is, node_id) || gated) ok = true; else again = true; }
+            if (!again) wf_store_hit(q, at, ok, h);
+        }
+        return again;
+    }
+};
+template <int FEAT>
+__global__ void __launch_bounds__(kBlock, NR_WF_OCC_RF) k_wf_closest_rf(DScene S, WfQueue q, uint32_t* spill, uint32_t* claim_next, uint32_t* clear_next) {
+    __shared__ uint32_t lds_stack[kLdsStack * kBlock];
+    wf_clear_next(clear_next, kWfMaxSegs);
+    Stack st; WfStackInit::make(st, lds_stack, spill);
+    Cnt cnt; wf_cnt_init(cnt);
+    const uint32_t total_waves = gridDim.x * (kBlock / 64);
+    const uint32_t my_wave = blockIdx.x * (kBlock / 64) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    WfClaim work; work.init(claim_next, *q.nblocks * kWfChunksPerBlock, my_wave, total_waves);
+    WfClosestSource<FEAT> src{S, q, work};
+    src.init();
+    traverse_stream<false, FEAT>(S, st, src, cnt);
+}
+
+// The shadow rays of the items (chunk, light) of a queue (k_wf_shadow's arithmetic).
+template <int FEAT>
+struct WfShadowSource {
+    const DScene& S; const WfQueue& q; WfClaim& work; uint4* shres; Cnt& cnt;
+    uint32_t chunk, li, pos, nvalid; bool have, exhausted; // wave-uniform
+    uint32_t at, my_li;                                     // per lane
+    NR_DEV void init() { chunk = 0u; li = 0u; pos = 0u; nvalid = 0u; have = false; exhausted = false; at = 0u; my_li = 0u; }
+    NR_DEV bool more() const { return !exhausted; }
+    NR_DEV void refill(bool idle, bool& got, d3& o, d3& d, double& tlimit) {
+        const uint32_t lane = __lane_id(), nl = S.num_lights;
+        for (int round = 0; round < 3; ++round) {
+            if (!have) {
+                uint32_t it;
+                if (!work.get(it)) { exhausted = true; return; }
+                chunk = it / nl; li = it - chunk * nl;
+                nvalid = wf_chunk_valid(q, chunk); pos = 0u; have = nvalid != 0u;
+                if (!have) continue;
+            }
+            const bool want = idle && !got;
+            const unsigned long long m = __ballot(want);
+            if (m == 0ULL) return;
+            const uint32_t n = (uint32_t)__popcll(m), left = nvalid - pos, take = n < left ? n : left;
+            const uint32_t rank = (uint32_t)__popcll(m & ((1ULL << lane) - 1ULL));
+            if (want && rank < take) {
+                const uint32_t a = chunk * 64u + pos + rank;
+                Hit hit;
+                if (wf_load_hit(q, a, hit) && ((S.shade[wf_hit_node<FEAT>(S, hit)].flags >> 8) & 0xffu) == NRAYS_MAT_PHONG) {
+                    d3 ro, rd; wf_load_od(q, a, ro, rd);
+                    const LightRec& light = S.lights[li];
+                    unsigned long long key = 0ULL;
+                    if (light.radius != 0.0) { const uint4 k = q.kp[a]; key = ((unsigned long long)k.y << 32) | k.x; }
+                    const d3 lp = wf_light_pos(light, key, li, 0u);
+                    const d3 point = ro + rd * hit.t;
+                    d3 ldir = lp - point;
+                    const double nrm = norm(ldir);
+                    ldir = ldir / nrm;
+                    cnt.shadow++;
+                    o = point + ldir * 0.001; d = ldir; tlimit = nrm - 0.001; at = a; my_li = li; got = true;
+                }
+            }
+            pos += take;
+            if (pos >= nvalid) have = false;
+        }
+    }
+    NR_DEV bool deliver(bool fin, d3 o, d3 d, bool hit, const Hit& h, bool blocked, f3 filter, bool gated) {
+        (void)o; (void)d; (void)hit; (void)h; (void)gated;
+        if (fin) shres[(size_t)my_li * q.slots + at] = make_uint4(blocked ? 1u : 0u, __float_as_uint(filter.x), __float_as_uint(filter.y), __float_as_uint(filter.z));
+        return false;
+    }
+};
+template <int FEAT>
+__global__ void __launch_bounds__(kBlock, NR_WF_OCC_RF) k_wf_shadow_rf(DScene S, WfQueue q, uint4* __restrict__ shres, DeviceCounters* ctr, uint32_t* spill, uint32_t* claim_next, uint32_t* clear_next) {
+    __shared__ uint32_t lds_stack[kLdsStack * kBlock];
+    wf_clear_next(clear_next, kWfMaxSegs);
+    Stack st; WfStackInit::make(st, lds_stack, spill);
+    Cnt cnt; wf_cnt_init(cnt);
+    const uint32_t total_waves = gridDim.x * (kBlock / 64);
+    const uint32_t my_wave = blockIdx.x * (kBlock / 64) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    WfClaim work; work.init(claim_next, *q.nblocks * kWfChunksPerBlock * S.num_lights, my_wave, total_waves);
+    WfShadowSource<FEAT> src{S, q, work, shres, cnt};
+    src.init();
+    traverse_stream<true, FEAT>(S, st, src, cnt);
+    wf_flush(ctr, cnt);
+}
+
 // ================================================================================================ host side
 #define WF_TRY(expr)                                                                                               \
     do {                                                                                                           \
@@ -564,6 +805,7 @@ struct WavefrontState {
     uint4* d_shres = nullptr; size_t shres_vecs = 0;
     float* d_acc = nullptr; size_t acc_floats = 0;
     uint64_t max_paths = 64ull << 20; // NRAYS_WF_MAX_PATHS: (pixel, sample) paths per pass over a range of wave tiles
+    bool refill = true;               // NRAYS_WF_REFILL=0: the traversal stages run every 64 rays from start to end together (traverse()) instead of refilling free lanes
     bool fuse = false;                // NRAYS_WF_FUSE=1: single-light scenes trace their shadow ray inside k_wf_shade instead of k_wf_shadow (A/B)
 };
 
@@ -574,6 +816,7 @@ static int wf_ensure(NraysScene* sc, uint32_t slots, size_t shres_vecs, size_t a
         WavefrontState& w = *sc->wf;
         if (const char* e = getenv("NRAYS_WF_MAX_PATHS")) w.max_paths = (uint64_t)std::max(4096ll, atoll(e));
         if (const char* e = getenv("NRAYS_WF_FUSE")) w.fuse = atoi(e) != 0;
+        if (const char* e = getenv("NRAYS_WF_REFILL")) w.refill = atoi(e) != 0; // 2: also in anti-aliased frames
         WF_TRY(hipMalloc((void**)&w.d_nblocks, (kMaxGenerations + 2) * sizeof(uint32_t)));
         WF_TRY(hipHostMalloc((void**)&w.h_nblocks, 4 * sizeof(uint32_t), hipHostMallocDefault));
         for (int k = 0; k < 2; ++k) {
@@ -652,7 +895,10 @@ static int wf_render_feat(NraysScene* sc, const NraysRenderParams* p, DRender R,
     const uint32_t lane_log2 = R.lane_log2, spp = p->ray_per_pixel;
     const uint32_t nwt = lane_log2 ? R.win_nx * R.win_ny : R.win_nx * R.win_ny * 4u;
     const uint64_t paths_per_tile = (uint64_t)(64u >> lane_log2) * spp;
-    const uint32_t grid_full = std::min<uint32_t>((uint32_t)kMaxGrid, (uint32_t)sc->num_cus * (uint32_t)NR_WF_OCC);
+    // lane refill pays where the lanes of a wave part ways early (one ray per pixel: hairball 2.98 -> 2.67 ms); the samples of ONE pixel walk
+    // together, and mixing in the next pixel's costs them their wave-uniform node fetches (16 spp: 22.0 -> 26.5 ms) — profiles/r04_wavefront_refill_ab.log
+    const bool refill_on = (sc->wf ? sc->wf->refill : !(getenv("NRAYS_WF_REFILL") && atoi(getenv("NRAYS_WF_REFILL")) == 0)) && (lane_log2 == 0u || (getenv("NRAYS_WF_REFILL") && atoi(getenv("NRAYS_WF_REFILL")) == 2));
+    const uint32_t grid_full = std::min<uint32_t>((uint32_t)kMaxGrid, (uint32_t)sc->num_cus * (uint32_t)(refill_on ? NR_WF_OCC_RF : NR_WF_OCC));
     const uint32_t waves_full = grid_full * (kBlock / 64);
     // tile ranges: every sample of a range's pixels in one pass (the samples of a pixel stay side by side in the queues)
     uint64_t max_paths = 64ull << 20;
@@ -682,7 +928,10 @@ static int wf_render_feat(NraysScene* sc, const NraysRenderParams* p, DRender R,
         {
             uint32_t* cn = claim(); uint32_t* cl = w.d_claim[w.claim_parity];
             uint32_t* zc = first_pass ? next_counts : nullptr; DeviceCounters* zctr = first_pass ? next_ctr : nullptr;
-            if (plain) hipLaunchKernelGGL((k_wf_primary<FEAT, true>), dim3(grid_full), dim3(kBlock), 0, stream, sc->d, R, q0, d_out, acc, sc->d_counters, sc->d_spill, tiles_x, tiles_y, t0, t1, cn, cl, zc, zctr);
+            if (refill_on) {
+                if (plain) hipLaunchKernelGGL((k_wf_primary_rf<FEAT, true>), dim3(grid_full), dim3(kBlock), 0, stream, sc->d, R, q0, d_out, acc, sc->d_counters, sc->d_spill, tiles_x, tiles_y, t0, t1, cn, cl, zc, zctr);
+                else hipLaunchKernelGGL((k_wf_primary_rf<FEAT, false>), dim3(grid_full), dim3(kBlock), 0, stream, sc->d, R, q0, d_out, acc, sc->d_counters, sc->d_spill, tiles_x, tiles_y, t0, t1, cn, cl, zc, zctr);
+            } else if (plain) hipLaunchKernelGGL((k_wf_primary<FEAT, true>), dim3(grid_full), dim3(kBlock), 0, stream, sc->d, R, q0, d_out, acc, sc->d_counters, sc->d_spill, tiles_x, tiles_y, t0, t1, cn, cl, zc, zctr);
             else hipLaunchKernelGGL((k_wf_primary<FEAT, false>), dim3(grid_full), dim3(kBlock), 0, stream, sc->d, R, q0, d_out, acc, sc->d_counters, sc->d_spill, tiles_x, tiles_y, t0, t1, cn, cl, zc, zctr);
             WF_TRY(hipGetLastError());
         }
@@ -692,14 +941,16 @@ static int wf_render_feat(NraysScene* sc, const NraysRenderParams* p, DRender R,
             q.nblocks = w.d_nblocks + g; qn.nblocks = w.d_nblocks + g + 1;
             if (g > 0) {
                 uint32_t* cn = claim(); uint32_t* cl = w.d_claim[w.claim_parity];
-                hipLaunchKernelGGL((k_wf_closest<FEAT>), dim3(grid), dim3(kBlock), 0, stream, sc->d, q, sc->d_spill, cn, cl);
+                if (refill_on) hipLaunchKernelGGL((k_wf_closest_rf<FEAT>), dim3(grid), dim3(kBlock), 0, stream, sc->d, q, sc->d_spill, cn, cl);
+                else hipLaunchKernelGGL((k_wf_closest<FEAT>), dim3(grid), dim3(kBlock), 0, stream, sc->d, q, sc->d_spill, cn, cl);
                 WF_TRY(hipGetLastError());
             }
             const bool fused = !kMulti && w.fuse;
             if (!fused) {
                 const uint32_t grid_sh = g == 0 ? grid_full : std::min<uint32_t>(grid_full, grid * sc->d.num_lights);
                 uint32_t* cn = claim(); uint32_t* cl = w.d_claim[w.claim_parity];
-                hipLaunchKernelGGL((k_wf_shadow<FEAT>), dim3(grid_sh), dim3(kBlock), 0, stream, sc->d, q, w.d_shres, sc->d_counters, sc->d_spill, cn, cl);
+                if (refill_on) hipLaunchKernelGGL((k_wf_shadow_rf<FEAT>), dim3(grid_sh), dim3(kBlock), 0, stream, sc->d, q, w.d_shres, sc->d_counters, sc->d_spill, cn, cl);
+                else hipLaunchKernelGGL((k_wf_shadow<FEAT>), dim3(grid_sh), dim3(kBlock), 0, stream, sc->d, q, w.d_shres, sc->d_counters, sc->d_spill, cn, cl);
                 WF_TRY(hipGetLastError());
             }
             const bool emit = can_continue && g < (uint32_t)kMaxGenerations;

@@ -17,6 +17,13 @@ pytestmark = pytest.mark.gpu
 CLASSES = ("rays_primary", "rays_reflection", "rays_refraction", "rays_shadow", "generations")
 
 
+@pytest.fixture(params=["2", "0"], autouse=True, ids=["refill", "norefill"])
+def refill(request, monkeypatch):
+    """Both forms of the traversal stages: lanes refilled from the wave's ray stream (stream_device.h: traverse_stream, the default)
+    and 64 rays run from start to end together (traverse())."""
+    monkeypatch.setenv("NRAYS_WF_REFILL", request.param)
+
+
 def _render(make, w, h, frames=1, **kw):
     sc, cam = make()
     p, _ = su.camera_params(cam, w, h, **kw)
