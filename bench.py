@@ -78,26 +78,38 @@ def camera_params(cam, W, H):
     return nr.make_params((W, H), cam.get("spp", 1), cam.get("window", 0.0), cam["eye"], proj, seed=cam.get("seed", 0))
 
 
+L2_PEAK_GBS = 34500.0  # same guide, "L2 (per XCD)": 32 MiB aggregate, ~34.5 TB/s
+
+
 def roofline_block(pk, tst, W, owned_rows, scene_bytes, pmc, pmc_source, tile_costs=None):
-    """SURVEY 8d roofline of the dominant kernel (k_primary): the contract fields (achieved = algorithmic bytes / kernel time
-    against the HBM peak) plus what the counters say actually bounds it: `bound` names the measured limiter
-    and `limiter.frac` is the kernel time that limiter accounts for."""
-    bytes_primary = pk.algorithmic_bytes(W, owned_rows)
+    """Roofline of the dominant kernel (k_primary).
+
+    `frac` = the LARGEST of the kernel's utilisations of real ceilings, each <= 1 by construction:
+      hbm    DRAM bytes moved (PMC FETCH_SIZE / WRITE_SIZE, the guide's gfx950 corrections) / kernel time / 8 TB/s
+      l2     bytes the waves actually request from the L2s (TCC requests x 128 B: a wave-uniform scalar node fetch is ONE
+             request, not 64) / kernel time / 34.5 TB/s
+      valu   SIMD cycles with a VALU instruction issuing (SQ_ACTIVE_INST_VALU x 4) / SIMD cycles of the kernel at 2.4 GHz
+    `bound` names that ceiling; `achieved` / `peak` / `unit` are its numbers.  The SURVEY 8(d) figure — algorithmic record
+    bytes of the tests actually run (no 64 B "ray record": rays live in registers; wave tiles decided by the screen bounds run
+    no test) / kernel time / HBM peak — is kept as `contract_*`: a rate of useful record bytes served mostly from caches, which
+    can exceed 1 and is NOT a utilisation.  `limiter` says what the schedule is waiting for (longest wave tile vs sum of tile
+    cycles per resident wave, from the library's per-tile cycle counts)."""
     t = tst.kernel_ms_primary * 1e-3
-    achieved = bytes_primary / t / 1e9 if t > 0 else 0.0
     fb = 12 * W * owned_rows
-    r = {"bound": "hbm", "contract_bound": "hbm", "kernel": "k_primary", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "traffic_source": None,
-         "algorithmic_bytes_per_launch": int(bytes_primary), "kernel_ms": round(tst.kernel_ms_primary, 5),
+    record_bytes = 32 * pk.node_tests + 36 * pk.tri_tests + 64 * pk.prim_tests + 64 * pk.hit_records + 16 * pk.tex_samples + fb
+    contract = record_bytes / t / 1e9 if t > 0 else 0.0
+    r = {"bound": None, "contract_bound": "hbm", "kernel": "k_primary", "achieved": None, "peak": None, "unit": None, "frac": None,
+         "traffic": None, "traffic_source": None, "ceilings": {},
+         "contract_achieved": round(contract, 2), "contract_peak": HBM_PEAK_GBS, "contract_unit": "GB/s", "contract_frac": round(contract / HBM_PEAK_GBS, 5),
+         "algorithmic_bytes_per_launch": int(record_bytes), "kernel_ms": round(tst.kernel_ms_primary, 5),
          "frame_gpu_ms": round(tst.kernel_ms_total, 5), "launches_timed": int(tst.frames_timed),
          "compulsory_bytes": int(scene_bytes + fb),
-         "units_per_launch": {"rays": int(pk.total_rays()), "node_tests": int(pk.node_tests), "tri_tests": int(pk.tri_tests),
+         "units_per_launch": {"rays": int(pk.total_rays()), "rays_traced": int(pk.rays_traced()), "node_tests": int(pk.node_tests), "tri_tests": int(pk.tri_tests),
                               "prim_tests": int(pk.prim_tests), "hit_records": int(pk.hit_records), "tex_samples": int(pk.tex_samples)},
-         "note": "achieved / frac = algorithmic record bytes (SURVEY 8d formula; every primary ray counts its root-box tests, as the "
-                 "reference would run them) / kernel time / HBM peak: a rate of useful record bytes, NOT a DRAM utilisation — the "
-                 "scenes are cache-resident (dram_frac) and most node fetches are scalar loads since round 3. `bound` is the "
-                 "measured limiter: the persistent kernel cannot end before its longest 8x8 wave tile does (one pixel chain of "
-                 "dependent traversals) nor before sum-of-tile-cycles / resident waves have passed (limiter block)"}
+         "note": "frac = max over real ceilings (hbm: PMC DRAM bytes, l2: TCC requests x 128 B, valu: VALU-issue cycles), each <= 1; "
+                 "contract_* = SURVEY 8d algorithmic record bytes of the tests actually run / kernel time / HBM peak (a rate of useful bytes "
+                 "served from caches and SGPR broadcasts, may exceed 1, not a utilisation); the kernels are latency-bound (wave_wait_frac): "
+                 "`limiter` names what the schedule waits for"}
     if tile_costs is not None and t > 0 and tile_costs.tiles:
         # shader cycles -> seconds at the guide's 2.4 GHz maximum (the clock under load is lower: the fractions are lower bounds)
         longest = tile_costs.max_cycles / CLOCK_HZ
@@ -108,16 +120,27 @@ def roofline_block(pk, tst, W, owned_rows, scene_bytes, pmc, pmc_source, tile_co
                "source": "nrays_get_tile_costs: s_memtime cycles of every wave tile of this camera's cost-recording frame"}
         lim["name"] = "latency/longest-tile" if longest >= through else "throughput/wave-cycles"
         lim["frac"] = round(max(longest, through) / t, 4)
-        r["bound"] = lim["name"]
         r["limiter"] = lim
     if pmc and t > 0:
         r["traffic_source"] = pmc_source
+        ceil = r["ceilings"]
         if pmc.get("hbm_bytes_per_launch") is not None:
             r["traffic"] = float(pmc["hbm_bytes_per_launch"])
-            r["dram_frac"] = round(pmc["hbm_bytes_per_launch"] / t / 1e9 / HBM_PEAK_GBS, 5)
+            a = pmc["hbm_bytes_per_launch"] / t / 1e9
+            ceil["hbm"] = {"achieved": round(a, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(min(a / HBM_PEAK_GBS, 1.0), 5)}
+            r["dram_frac"] = ceil["hbm"]["frac"]
         simd_cycles = NUM_SIMDS * t * CLOCK_HZ
+        if pmc.get("TCC_HIT_sum") is not None and pmc.get("TCC_MISS_sum") is not None:
+            req = pmc["TCC_HIT_sum"] + pmc["TCC_MISS_sum"]
+            a = req * 128.0 / t / 1e9  # 128-byte L2 requests (MI355X_MICROARCH.md, HBM section)
+            ceil["l2"] = {"achieved": round(a, 1), "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": round(min(a / L2_PEAK_GBS, 1.0), 5)}
+            r["l2_hit_rate"] = round(pmc["TCC_HIT_sum"] / max(req, 1.0), 4)
+            r["l2_gbs"] = ceil["l2"]["achieved"]
         if pmc.get("SQ_ACTIVE_INST_VALU") is not None:  # quad-cycles summed over waves
-            r["valu_active_frac"] = round(4.0 * pmc["SQ_ACTIVE_INST_VALU"] / simd_cycles, 4)
+            a = 4.0 * pmc["SQ_ACTIVE_INST_VALU"] / t
+            ceil["valu"] = {"achieved": round(a / 1e9, 2), "peak": round(NUM_SIMDS * CLOCK_HZ / 1e9, 1), "unit": "G SIMD-cycles/s with a VALU instruction issuing",
+                            "frac": round(min(4.0 * pmc["SQ_ACTIVE_INST_VALU"] / simd_cycles, 1.0), 4)}
+            r["valu_active_frac"] = ceil["valu"]["frac"]
         if pmc.get("SQ_WAIT_ANY") is not None and pmc.get("SQ_WAVE_CYCLES"):
             r["wave_wait_frac"] = round(pmc["SQ_WAIT_ANY"] / pmc["SQ_WAVE_CYCLES"], 4)  # share of the waves' lifetime spent in s_waitcnt
         f64 = [pmc.get(k) for k in ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_TRANS_F64")]
@@ -128,12 +151,14 @@ def roofline_block(pk, tst, W, owned_rows, scene_bytes, pmc, pmc_source, tile_co
             r["valu_wave_instructions"] = int(pmc["SQ_INSTS_VALU"])
         if pmc.get("SQ_INSTS_VMEM_RD") is not None:
             r["vector_load_wave_instructions"] = int(pmc["SQ_INSTS_VMEM_RD"])
-        if pmc.get("TCC_HIT_sum") is not None and pmc.get("TCC_MISS_sum") is not None:
-            req = pmc["TCC_HIT_sum"] + pmc["TCC_MISS_sum"]
-            r["l2_hit_rate"] = round(pmc["TCC_HIT_sum"] / max(req, 1.0), 4)
-            r["l2_gbs"] = round(req * 128.0 / t / 1e9, 1)  # 128-byte L2 requests (MI355X_MICROARCH.md §HBM)
         if pmc.get("errors"):
             r["pmc_errors"] = pmc["errors"][:2]
+        if ceil:
+            name = max(ceil, key=lambda k: ceil[k]["frac"])
+            r["bound"] = name
+            r["achieved"], r["peak"], r["unit"], r["frac"] = ceil[name]["achieved"], ceil[name]["peak"], ceil[name]["unit"], ceil[name]["frac"]
+    if r["frac"] is None:
+        r["bound"] = "unmeasured: no hardware counters in this run (contract_* only)"
     return r
 
 
@@ -147,7 +172,7 @@ def pmc_for(workload, W, H, live):
                 return res, "live: rocprofv3 --pmc (2 passes, tools/pmc_collect.py TRAFFIC_PASSES) on tools/kbench.py --child %s in this run" % workload
         except Exception as e:  # the bench line must not depend on the profiler
             print("live PMC collection failed: %r" % (e,), file=sys.stderr)
-    for rnd in ("r03", "r02"):
+    for rnd in ("r04", "r03", "r02"):
         path = os.path.join(ROOT, "profiles", "%s_pmc_%s.json" % (rnd, workload))
         if os.path.exists(path) and (W, H) == (1920, 1080):
             try:
@@ -179,14 +204,34 @@ def cpu_baseline(scene, params, budget_s):
         spent += sec
         per_frame = sec / reps
     rays = max(st.total_rays(), 1)
-    sample = "%d x full %dx%d frame, %d rays, %.2f s wall on %d persistent threads (%.0f CPU-s), BVT build excluded, sized from a warm call" % (
-        reps, params.width, params.height, rays, sec, cores, sec * cores)
+    cpu_sum, cpu_min, cpu_max = oracle.last_thread_cpu()  # CLOCK_THREAD_CPUTIME_ID of every worker thread, gate to last pixel
+    sample = ("%d x full %dx%d frame, %d rays, %.2f s wall on %d persistent threads; CPU time of the threads: %.1f s in all, %.3f s the least "
+              "loaded, %.3f s the most (static contiguous pixel ranges, scene.rs:61-63: the wall time is the slowest thread's); BVT build "
+              "excluded, sized from a warm call") % (reps, params.width, params.height, rays, sec, cores, cpu_sum, cpu_min, cpu_max)
     # the same rays through the reference-equivalent tree (median split, one primitive per leaf, best-first
     # search), reported beside the shipped BVH's counts in roofline.units_per_launch
     ref_counts = {"aabb_tests_per_ray": round(st.node_tests / rays, 2), "tri_tests_per_ray": round(st.tri_tests / rays, 2),
                   "prim_tests_per_ray": round(st.prim_tests / rays, 3)}
     return {"value": round(rays / sec / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port", "sample": sample,
-            "sample_seconds": round(sec, 3), "reference_tree_counts": ref_counts}
+            "sample_seconds": round(sec, 3), "thread_cpu_seconds": {"sum": round(cpu_sum, 3), "min": round(cpu_min, 4), "max": round(cpu_max, 4)},
+            # what the host actually gave the threads (a container's CPU quota can be far below the logical CPUs it shows)
+            "effective_cores": round(cpu_sum / max(sec, 1e-9), 1), "cpu_quota": cpu_quota(),
+            "value_at_perfect_balance": round(rays / max(cpu_sum / cores, 1e-9) / 1e6, 4),
+            "reference_tree_counts": ref_counts}
+
+
+def cpu_quota():
+    """The container's CPU quota in cores (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited / unknown."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else round(float(q) / float(per), 2)
+    except Exception:
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else round(q / per, 2)
+    except Exception:
+        return None
 
 
 def reference_toolchain_probe():
@@ -403,7 +448,13 @@ def run_single(args):
         # BASELINE config 3 / the north star's ">= 100x CPU on crytek_sponza at 1 GPU", and the hairball (BVH stress): same process, same run
         sec_steps, sec_warm = max(10, min(args.steps, 60)), max(3, min(args.warmup, 10))
         result["secondary"] = {"sponza_standin": single_gpu_measure("sponza", W, H, sec_steps, sec_warm, args),
-                               "hairball_standin": single_gpu_measure("hairball", W, H, max(10, min(args.steps, 30)), sec_warm, args, pmc=False, moving=False)}
+                               "hairball_standin": single_gpu_measure("hairball", W, H, max(10, min(args.steps, 30)), sec_warm, args, moving=False)}
+    sp = result.get("secondary", {}).get("sponza_standin", m if args.scene == "sponza" else None)
+    if sp and "gpu_over_cpu" in sp:
+        # the north star's ">= 100x CPU-baseline Mrays/s on crytek_sponza at 1 GPU", on the stand-in; both legs count the same rays
+        result["north_star_sponza_gpu_over_cpu"] = sp["gpu_over_cpu"]
+        result["north_star_sponza"] = {"gpu_mrays_s": sp["value"], "gpu_mrays_s_traced": sp["value_traced"], "cpu_mrays_s": sp["cpu_baseline"]["value"],
+                                       "cpu_cores": sp["cpu_baseline"]["cores"], "target": 100.0}
     result["reference_toolchain"] = reference_toolchain_probe()
     return result
 
@@ -482,6 +533,15 @@ def tiled_measure(name, W, H, steps, warmup, rank, world, owners):
         dist.all_reduce(dt_t, op=dist.ReduceOp.MAX)
         dt = float(dt_t.item())
     tst = ss.stats()  # HIP-event timings of this rank's first owner over the timed steps
+    # where a frame spends its time on every rank (nrays_multi_get_timings: events on the owner's render / communication streams)
+    tm = ss.timings()
+    tm_t = torch.tensor([tm.render_ms, tm.exchange_ms, tm.untile_ms, float(tm.owner)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        all_tm = [torch.zeros_like(tm_t) for _ in range(world)]
+        dist.all_gather(all_tm, tm_t)
+    else:
+        all_tm = [tm_t]
+    per_rank = [{"owner": int(v[3].item()), "render_ms": round(v[0].item(), 4), "exchange_ms": round(v[1].item(), 4), "untile_ms": round(v[2].item(), 4)} for v in all_tm]
 
     check = None
     if rank == 0:  # the gathered, un-permuted frame equals a direct single-GPU render of the whole frame (untimed)
@@ -496,6 +556,8 @@ def tiled_measure(name, W, H, steps, warmup, rank, world, owners):
         owned = len(tiling.owned_rows(H, band, owner0, owners))
         res = {"value": round(rays_total * steps / dt / 1e6, 3), "unit": "Mrays/s", "steps": steps, "warmup": warmup,
                "ms_per_step": round(dt / steps * 1e3, 5), "value_traced": round(traced * steps / dt / 1e6, 3),
+               # per rank (one process per GPU) or of the first owner (one process for all owners): tile render / exchange / un-permute
+               "per_rank_ms": per_rank,
                "config": {"workload": desc % (W, H), "resolution": [W, H], "ray_per_pixel": int(cam.get("spp", 1)), "parallelism": mode,
                           "tiled_frame_identical_to_single_gpu_render": check,
                           "rays_per_frame": {"total": int(rays_total), "primary": int(rays_t[1].item()), "reflection": int(rays_t[2].item()),
@@ -521,7 +583,8 @@ def run_tiled(args, rank, world, owners):
         return None
     result = {"metric": METRIC, "value": m["value"], "unit": "Mrays/s", "n_gpus": owners, "steps": args.steps, "warmup": args.warmup,
               "ms_per_step": m["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-              "dtype": "f64", "data": "synthetic", "config": m["config"], "value_traced": m["value_traced"], "roofline": m["roofline"]}
+              "dtype": "f64", "data": "synthetic", "config": m["config"], "value_traced": m["value_traced"], "per_rank_ms": m["per_rank_ms"],
+              "roofline": m["roofline"]}
     if sec is not None:
         result["secondary"] = {"config4_sponza_standin_4k_8_lights": sec}
     return result

@@ -325,6 +325,18 @@ int nrays_render_multi_device(NraysSceneSet* set, const NraysRenderParams* param
 int nrays_multi_sync(NraysSceneSet* set);
 /* Counters of the last frame summed over the owners this process drives. */
 int nrays_multi_get_stats(NraysSceneSet* set, NraysStats* out_stats);
+/* Where a frame of the group spends its time on THIS process's first owner, averaged over the frames since the previous call
+ * (HIP events on the owner's render / communication streams): the tile render (nrays_render_device), the exchange (owner 0: its own
+ * tile copy + every receive; other owners: their send) and, on owner 0, the un-permute (k_untile).  The reference's analogue is the
+ * join of its render threads, src/scene.rs:97-112. */
+typedef struct NraysMultiTimings {
+    double render_ms;
+    double exchange_ms;
+    double untile_ms;
+    uint32_t frames;   /* frames averaged */
+    uint32_t owner;    /* band owner the figures belong to */
+} NraysMultiTimings;
+int nrays_multi_get_timings(NraysSceneSet* set, NraysMultiTimings* out_timings);
 
 const char* nrays_last_error(void);
 

@@ -128,6 +128,16 @@ pub struct NraysRenderParams {
 
 #[repr(C)]
 #[derive(Clone, Copy, Default)]
+pub struct NraysMultiTimings {
+    pub render_ms: f64,
+    pub exchange_ms: f64,
+    pub untile_ms: f64,
+    pub frames: u32,
+    pub owner: u32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
 pub struct NraysStats {
     pub rays_primary: u64,
     pub rays_reflection: u64,
@@ -203,4 +213,5 @@ extern "C" {
     pub fn nrays_render_multi_device(set: *mut NraysSceneSet, params: *const NraysRenderParams, out_rgb_device: *mut f32) -> c_int;
     pub fn nrays_multi_sync(set: *mut NraysSceneSet) -> c_int;
     pub fn nrays_multi_get_stats(set: *mut NraysSceneSet, out_stats: *mut NraysStats) -> c_int;
+    pub fn nrays_multi_get_timings(set: *mut NraysSceneSet, out_timings: *mut NraysMultiTimings) -> c_int;
 }

@@ -95,6 +95,10 @@ class NraysStats(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+class NraysMultiTimings(C.Structure):
+    _fields_ = [("render_ms", C.c_double), ("exchange_ms", C.c_double), ("untile_ms", C.c_double), ("frames", C.c_uint32), ("owner", C.c_uint32)]
+
+
 class NraysTileCosts(C.Structure):
     _fields_ = [("tiles", C.c_uint64), ("sum_cycles", C.c_uint64), ("max_cycles", C.c_uint64), ("resident_waves", C.c_uint64)]
 
@@ -134,6 +138,7 @@ HIP_SYMBOLS = {
     "nrays_render_multi_device": (C.c_int, [C.c_void_p, C.POINTER(NraysRenderParams), C.c_void_p]),
     "nrays_multi_sync": (C.c_int, [C.c_void_p]),
     "nrays_multi_get_stats": (C.c_int, [C.c_void_p, C.POINTER(NraysStats)]),
+    "nrays_multi_get_timings": (C.c_int, [C.c_void_p, C.POINTER(NraysMultiTimings)]),
     "nrays_last_error": (C.c_char_p, []),
     "nrays_abi_version": (C.c_uint32, []),
 }

@@ -87,6 +87,12 @@ struct NraysSceneSet {
         hipEvent_t rendered[2] = {nullptr, nullptr};  // tile[slot] is complete
         hipEvent_t sent[2] = {nullptr, nullptr};      // tile[slot] has left (may be rendered into again)
     };
+    // nrays_multi_get_timings: timing-enabled events around the first local owner's stages, a ring of the last frames
+    static constexpr int kTimed = 64;
+    hipEvent_t t_render0[kTimed] = {}, t_render1[kTimed] = {}, t_exch0[kTimed] = {}, t_exch1[kTimed] = {}, t_untile1[kTimed] = {};
+    bool t_has_exchange[kTimed] = {}, t_has_untile[kTimed] = {};
+    uint64_t t_recorded = 0, t_reported = 0;
+    bool t_ready = false;
     std::vector<Owner> local;     // the owners this process drives
     // owner 0's side (present iff this process drives owner 0)
     float* gathered[2] = {nullptr, nullptr};
@@ -149,7 +155,10 @@ int nrays_comm_create_local(uint32_t num_owners, const int32_t* devices, NraysCo
     return NRAYS_OK;
 }
 
-static void poison(NraysComm* c) { // ncclCommAbort releases the communicator: nothing is left to destroy afterwards
+// ncclCommAbort releases THIS process's communicators (nothing is left to destroy afterwards) and makes later calls on the group fail fast.
+// It does not release a peer process that already sits in its own grouped call or stream kernel: peers have to time out or be aborted by
+// their own process (in one-process mode every owner's communicator is aborted here).
+static void poison(NraysComm* c) {
     if (c->poisoned) return;
     c->poisoned = true;
     for (size_t i = 0; i < c->comms.size(); ++i) { (void)hipSetDevice(c->comm_devices[i]); (void)ncclCommAbort(c->comms[i]); }
@@ -187,6 +196,13 @@ void nrays_scene_set_destroy(NraysSceneSet* s) {
         if (o.render_stream) (void)hipStreamDestroy(o.render_stream);
         if (o.comm_stream) (void)hipStreamDestroy(o.comm_stream);
     }
+    if (s->t_ready && !s->local.empty()) {
+        (void)hipSetDevice(s->local[0].device);
+        for (int k = 0; k < NraysSceneSet::kTimed; ++k) {
+            (void)hipEventDestroy(s->t_render0[k]); (void)hipEventDestroy(s->t_render1[k]); (void)hipEventDestroy(s->t_exch0[k]);
+            (void)hipEventDestroy(s->t_exch1[k]); (void)hipEventDestroy(s->t_untile1[k]);
+        }
+    }
     if (s->has_root()) {
         (void)hipSetDevice(s->local[0].device);
         for (int k = 0; k < 2; ++k) if (s->gathered[k]) (void)hipFree(s->gathered[k]);
@@ -217,6 +233,15 @@ int nrays_scene_set_create(const NraysSceneDesc* desc, NraysComm* comm, NraysSce
             if (hipEventCreateWithFlags(&o.rendered[b], hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&o.sent[b], hipEventDisableTiming) != hipSuccess) { s->local.push_back(o); return bail(nrays::set_last_error(NRAYS_ERR_HIP, "event creation failed")); }
         s->local.push_back(o);
+    }
+    if (!s->local.empty()) { // timing events of the first local owner (nrays_multi_get_timings)
+        if (hipSetDevice(s->local[0].device) != hipSuccess) return bail(nrays::set_last_error(NRAYS_ERR_HIP, "hipSetDevice failed"));
+        bool ok = true;
+        for (int k = 0; k < NraysSceneSet::kTimed && ok; ++k)
+            ok = hipEventCreate(&s->t_render0[k]) == hipSuccess && hipEventCreate(&s->t_render1[k]) == hipSuccess && hipEventCreate(&s->t_exch0[k]) == hipSuccess &&
+                 hipEventCreate(&s->t_exch1[k]) == hipSuccess && hipEventCreate(&s->t_untile1[k]) == hipSuccess;
+        if (!ok) return bail(nrays::set_last_error(NRAYS_ERR_HIP, "event creation failed"));
+        s->t_ready = true;
     }
     *out_set = s;
     return NRAYS_OK;
@@ -273,6 +298,8 @@ int nrays_render_multi_device(NraysSceneSet* s, const NraysRenderParams* params,
     if (rc != NRAYS_OK) return rc;
     const int slot = (int)(s->step & 1u);
     const size_t count = tile_floats_of(s, params); // this frame's tile size (the buffers may be larger: they only grow)
+    const int tslot = (int)(s->t_recorded % NraysSceneSet::kTimed);
+    s->t_has_exchange[tslot] = false; s->t_has_untile[tslot] = false;
 
     // 1. tile renders, each on its owner's render stream
     for (auto& o : s->local) {
@@ -281,8 +308,11 @@ int nrays_render_multi_device(NraysSceneSet* s, const NraysRenderParams* params,
         q.band_rows = owners > 1 ? kBandRows : 0; q.band_owner = o.index; q.band_owners = owners;
         if (s->step >= 2) MG_HIP(hipStreamWaitEvent(o.render_stream, o.sent[slot], 0)); // tile[slot] of frame k - 2 has left
         float* dst = (owners == 1) ? out_rgb_device : o.tile[slot];
+        const bool timed_owner = s->t_ready && &o == &s->local[0];
+        if (timed_owner) MG_HIP(hipEventRecord(s->t_render0[tslot], o.render_stream));
         rc = nrays_render_device(o.scene, &q, dst, (void*)o.render_stream);
         if (rc != NRAYS_OK) return rc;
+        if (timed_owner) MG_HIP(hipEventRecord(s->t_render1[tslot], o.render_stream));
         MG_HIP(hipEventRecord(o.rendered[slot], o.render_stream));
         MG_HIP(hipStreamWaitEvent(o.comm_stream, o.rendered[slot], 0));
     }
@@ -290,6 +320,7 @@ int nrays_render_multi_device(NraysSceneSet* s, const NraysRenderParams* params,
         // 2. the exchange: same-device owners copy, the others send / owner 0 receives (one grouped RCCL call)
         const int root_dev = c->ranked ? -1 : c->devices[0];
         NraysSceneSet::Owner* root = s->has_root() ? &s->local[0] : nullptr;
+        if (s->t_ready) { MG_HIP(hipSetDevice(s->local[0].device)); MG_HIP(hipEventRecord(s->t_exch0[tslot], s->local[0].comm_stream)); s->t_has_exchange[tslot] = true; }
         bool any_rccl = false;
         for (auto& o : s->local) {
             if (o.index == 0) continue;
@@ -343,15 +374,18 @@ int nrays_render_multi_device(NraysSceneSet* s, const NraysRenderParams* params,
             if (o.index == 0 && root) done_on = root->comm_stream;
             MG_HIP(hipEventRecord(o.sent[slot], done_on));
         }
+        if (s->t_ready) { MG_HIP(hipSetDevice(s->local[0].device)); MG_HIP(hipEventRecord(s->t_exch1[tslot], s->local[0].comm_stream)); }
         // 3. un-permute the bands on owner 0
         if (root) {
             MG_HIP(hipSetDevice(root->device));
             rc = nrays_untile_device(s->gathered[slot], out_rgb_device, params->width, params->height, kBandRows, owners, (void*)root->comm_stream);
             if (rc != NRAYS_OK) return rc;
+            if (s->t_ready) { MG_HIP(hipEventRecord(s->t_untile1[tslot], root->comm_stream)); s->t_has_untile[tslot] = true; }
         }
     }
     s->width = params->width; s->height = params->height;
     s->step++;
+    if (s->t_ready) s->t_recorded++;
     return NRAYS_OK;
 }
 
@@ -393,6 +427,32 @@ int nrays_render_multi(NraysSceneSet* s, const NraysRenderParams* params, float*
         MG_HIP(hipMemcpyAsync(out_rgb, s->frame, (size_t)params->width * params->height * 3 * sizeof(float), hipMemcpyDeviceToHost, last));
     }
     return nrays_multi_sync(s);
+}
+
+int nrays_multi_get_timings(NraysSceneSet* s, NraysMultiTimings* out) {
+    if (!s || !out) return nrays::set_last_error(NRAYS_ERR_BAD_ARG, "null argument");
+    std::memset(out, 0, sizeof *out);
+    if (!s->t_ready || s->local.empty()) return NRAYS_OK;
+    int rc = nrays_multi_sync(s);
+    if (rc != NRAYS_OK) return rc;
+    DeviceGuard guard;
+    MG_HIP(hipSetDevice(s->local[0].device));
+    uint64_t first = s->t_reported;
+    if (s->t_recorded - first > (uint64_t)NraysSceneSet::kTimed) first = s->t_recorded - NraysSceneSet::kTimed;
+    double r = 0.0, e = 0.0, u = 0.0; uint32_t n = 0;
+    for (uint64_t f = first; f < s->t_recorded; ++f) {
+        const int k = (int)(f % NraysSceneSet::kTimed);
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, s->t_render0[k], s->t_render1[k]) != hipSuccess) continue;
+        r += ms;
+        if (s->t_has_exchange[k] && hipEventElapsedTime(&ms, s->t_exch0[k], s->t_exch1[k]) == hipSuccess) e += ms;
+        if (s->t_has_untile[k] && hipEventElapsedTime(&ms, s->t_exch1[k], s->t_untile1[k]) == hipSuccess) u += ms;
+        ++n;
+    }
+    s->t_reported = s->t_recorded;
+    if (n) { out->render_ms = r / n; out->exchange_ms = e / n; out->untile_ms = u / n; }
+    out->frames = n; out->owner = s->local[0].index;
+    return NRAYS_OK;
 }
 
 // Ray-class counters of the last frame, summed over the owners this process drives (kernel timings: owner-0-local

@@ -584,6 +584,36 @@ __global__ void __launch_bounds__(1024) k_tile_order(const uint32_t* __restrict_
     if (order_len && threadIdx.x == 0u) order_len[x] = wg_total;
 }
 
+// A first guess of the wave-tile costs of a camera that has no history yet (the reference's caller renders every camera ONCE,
+// examples/loader3d.rs:67-93: the first frame is the one that counts for it).  A mesh frame is as long as its deepest chains, and a
+// chain is deep where the primary ray crosses many nodes that can continue it — alpha-mapped / transparent layers (scene.rs:229) and
+// mirrors (scene.rs:204).  cost = 1 + 4 x (boxes of such nodes the ray through the tile's centre pixel crosses), f32 slab tests against
+// their world AABBs: a few microseconds, and k_tile_order then starts those tiles first, as it does from recorded costs on later
+// frames.  Scheduling only: pixels do not depend on it.
+__global__ void k_seed_costs(DRender R, const float* __restrict__ boxes, uint32_t nboxes, uint32_t* __restrict__ cost, uint32_t nwt) {
+    const uint32_t wt = blockIdx.x * blockDim.x + threadIdx.x;
+    if (wt >= nwt) return;
+    const uint32_t tile = wt >> 2, sub = wt & 3u;
+    const uint32_t tx = R.win_x0 + tile % R.win_nx, ty = R.win_y0 + tile / R.win_nx;
+    const uint32_t i = tx * kTile + ((sub & 1u) << 3) + 4u, rl = ty * kTile + ((sub >> 1) << 3) + 4u;
+    uint32_t j = rl;
+    if (R.band_rows != 0 && R.band_owners > 1) j = ((rl / R.band_rows) * R.band_owners + R.band_owner) * R.band_rows + (rl % R.band_rows);
+    const double dx = ((double)i / (double)R.width - 0.5) * 2.0, dy = -((double)j / (double)R.height - 0.5) * 2.0;
+    double h[4];
+    for (int r = 0; r < 4; ++r) h[r] = R.m[r] * dx + R.m[4 + r] * dy - R.m[8 + r] + R.m[12 + r];
+    const float ox = (float)R.eye[0], oy = (float)R.eye[1], oz = (float)R.eye[2];
+    const float ix = 1.0f / (float)(h[0] / h[3] - R.eye[0]), iy = 1.0f / (float)(h[1] / h[3] - R.eye[1]), iz = 1.0f / (float)(h[2] / h[3] - R.eye[2]);
+    uint32_t n = 0u;
+    for (uint32_t b = 0; b < nboxes; ++b) {
+        const float* q = boxes + 6u * b;
+        float t0 = (q[0] - ox) * ix, t1 = (q[3] - ox) * ix; float lo = fminf(t0, t1), hi = fmaxf(t0, t1);
+        t0 = (q[1] - oy) * iy; t1 = (q[4] - oy) * iy; lo = fmaxf(lo, fminf(t0, t1)); hi = fminf(hi, fmaxf(t0, t1));
+        t0 = (q[2] - oz) * iz; t1 = (q[5] - oz) * iz; lo = fmaxf(lo, fminf(t0, t1)); hi = fminf(hi, fmaxf(t0, t1));
+        n += (hi >= fmaxf(lo, 0.0f)) ? 1u : 0u;
+    }
+    cost[wt] = 1u + 4u * n;
+}
+
 // Screen bounds of the scene for one camera: the pixel rectangle outside of which no primary ray can reach the scene's
 // bounding box, so that k_primary can write the background for whole wave tiles without generating their rays.
 // Raygen (generate_primary, scene.rs:74-89) sends the ray of sample position (ox, oy) from `eye` through
@@ -909,7 +939,10 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
     int occ = 0;
     if (!instrumented && (sc->features == 6 || sc->features == 7 || sc->features == 22 || sc->features == 23) && lane_log2 == 0u) {
         const uint64_t wave_tiles = (uint64_t)ntiles * 4u, waves2 = (uint64_t)sc->num_cus * 8u;
-        occ = ((sc->features & kFeatMultiSample) && sc->light_lsl && sc->light_split_factor != 0.0f) || wave_tiles >= 24u * waves2 ? 3 : 0;
+        // (multi-light frames: from 12 wave tiles per resident wave on — an owner's eighth of a 4K frame is as long as its longest tile even
+        // with that tile split, and ran 1.9 ms at two waves against 2.0 - 2.9 ms at three: profiles/r04_tile_scaling.log)
+        const bool multi = (sc->features & kFeatMultiSample) && sc->light_lsl && sc->light_split_factor != 0.0f;
+        occ = wave_tiles >= (multi ? 12u : 24u) * waves2 ? 3 : 0;
         if (sc->occ_override >= 0) occ = sc->occ_override == 3 ? 3 : 0;
     }
     uint32_t grid_primary = std::min<uint32_t>(std::min<uint32_t>(((ntiles + 7u) / 8u) * 8u, (uint32_t)kMaxGrid),
@@ -997,15 +1030,22 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
             R.tile_order = sc->d_tile_order;
             grab = 1u;
         } else {
-            if (sc->cost_valid && sc->cost_key == key) {
+            // no history for this geometry: a first guess from the boxes of the nodes that can continue a chain (k_seed_costs)
+            const bool seeded = !(sc->cost_valid && sc->cost_key == key) && sc->seed_enabled && sc->seed_boxes != 0u && lane_log2 == 0u && win_units > 0;
+            if (seeded) {
                 if (timed) HIP_TRY(hipEventRecord(sc->ev_begin[slot], stream));
+                hipLaunchKernelGGL(k_seed_costs, dim3((nwt + 255u) / 256u), dim3(256), 0, stream, R, (const float*)sc->d_seed_boxes, sc->seed_boxes, sc->d_tile_cost, nwt);
+                HIP_TRY(hipGetLastError());
+            }
+            if (seeded || (sc->cost_valid && sc->cost_key == key)) {
+                if (timed && !seeded) HIP_TRY(hipEventRecord(sc->ev_begin[slot], stream));
                 sc->has_prepass[slot] = true;
                 hipLaunchKernelGGL(k_tile_order, dim3(8), dim3(1024), 0, stream, sc->d_tile_cost, sc->d_tile_order, nwt, (unsigned long long*)nullptr,
                                    split_lsl, sc->light_split_factor, grid_primary * (uint32_t)(kBlock / 64), split_lsl ? sc->d_order_len : (uint32_t*)nullptr);
                 HIP_TRY(hipGetLastError());
                 R.tile_order = sc->d_tile_order;
                 grab = 1u;
-                sc->order_valid = true; sc->order_key = key; sc->order_cam = sc->cost_cam;
+                sc->order_valid = true; sc->order_key = key; sc->order_cam = seeded ? ~cam : sc->cost_cam; // (a guessed order is replaced by the recorded one on the next frame)
             }
             R.tile_cost = sc->d_tile_cost;
             sc->cost_key = key; sc->cost_cam = cam; sc->cost_valid = true;
@@ -1257,6 +1297,22 @@ int nrays_scene_create(const NraysSceneDesc* desc, NraysScene** out_scene) {
             sc->features |= kFeatLdsScene;
         }
       }
+    }
+    {   // k_seed_costs: world AABBs of the nodes that can continue a chain (transparent / alpha-mapped / reflective), as f32
+        std::vector<float> boxes;
+        for (size_t i = 0; i < h.shade.size() && boxes.size() < 6u * 2048u; ++i) {
+            const ShadeRec& sr = h.shade[i];
+            if (!(sr.alpha < 1.0f || h.shade_alpha_tex[i] >= 0 || sr.refl_mix != 0.0f)) continue;
+            const double* b = h.node_aabbs.data() + 6 * i;
+            bool finite = true;
+            for (int a = 0; a < 6; ++a) finite = finite && std::isfinite(b[a]) && std::fabs(b[a]) < 1e30;
+            if (!finite) continue;
+            for (int a = 0; a < 6; ++a) boxes.push_back((float)b[a]);
+        }
+        const float* dptr = nullptr;
+        if ((rc = upload(sc, boxes, &dptr)) != NRAYS_OK) return bail(rc);
+        sc->d_seed_boxes = dptr; sc->seed_boxes = (uint32_t)(boxes.size() / 6);
+        if (const char* e = getenv("NRAYS_COST_SEED")) sc->seed_enabled = atoi(e) != 0;
     }
     if (const char* e = getenv("NRAYS_MAX_PRIMARY")) { sc->max_primary_per_launch = (uint64_t)std::max(1ll, atoll(e)); sc->max_primary_forced = true; }
     if (const char* e = getenv("NRAYS_LANE_LOG2")) sc->lane_log2_override = std::max(0, std::min(6, atoi(e)));

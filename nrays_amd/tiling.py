@@ -154,6 +154,12 @@ class SceneSet:
         abi.check(self._lib.nrays_multi_get_stats(self._h, C.byref(st)))
         return st
 
+    def timings(self):
+        """Average render / exchange / un-permute milliseconds of this process's first owner over the frames since the previous call."""
+        tm = abi.NraysMultiTimings()
+        abi.check(self._lib.nrays_multi_get_timings(self._h, C.byref(tm)))
+        return tm
+
     def local_scenes(self):
         """[(owner index, NraysScene* handle)] of the owners this process drives (handles stay owned by the set)."""
         out = []

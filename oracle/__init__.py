@@ -33,6 +33,8 @@ def lib():
         l.nrays_oracle_render_timed.argtypes = [C.POINTER(abi.NraysSceneDesc), C.POINTER(abi.NraysRenderParams),
                                                 C.POINTER(C.c_float), C.c_int, C.c_int, C.POINTER(abi.NraysStats),
                                                 C.POINTER(C.c_double)]
+        l.nrays_oracle_last_thread_cpu.restype = None
+        l.nrays_oracle_last_thread_cpu.argtypes = [C.POINTER(C.c_double)]
         l.nrays_oracle_cast_batch.restype = C.c_int
         l.nrays_oracle_cast_batch.argtypes = [C.POINTER(abi.NraysSceneDesc), C.c_uint32, C.POINTER(C.c_double),
                                               C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double),
@@ -83,6 +85,13 @@ def render_timed(descriptor, params, num_threads, reps):
     if rc != 0:
         raise RuntimeError("oracle render failed: %d %s" % (rc, l.nrays_oracle_last_error()))
     return sec.value, st
+
+
+def last_thread_cpu():
+    """CPU seconds of the threads of the last render_timed call of this thread: (sum, min, max)."""
+    v = (C.c_double * 3)()
+    lib().nrays_oracle_last_thread_cpu(v)
+    return v[0], v[1], v[2]
 
 
 def cast(descriptor, origins, dirs, bruteforce=False):

@@ -1064,12 +1064,15 @@ typedef struct {
     size_t low, up; Counters cnt;
     int reps;                  /* the thread renders its range this many times (1 for a plain render) */
     pthread_barrier_t* start;  /* timed runs only */
+    double cpu_s; /* CPU time of this thread between the gate and its last pixel (timed runs) */
+    double t_begin, t_end; /* CLOCK_MONOTONIC when this thread left the gate / wrote its last pixel (timed runs) */
 } Job;
 
 static void* render_job(void* arg) {
     Job* jb = (Job*)arg;
     const NraysRenderParams* p = jb->p;
-    if (jb->start) pthread_barrier_wait(jb->start); /* timed runs: all threads leave the gate together */
+    struct timespec c0, c1;
+    if (jb->start) { pthread_barrier_wait(jb->start); clock_gettime(CLOCK_THREAD_CPUTIME_ID, &c0); clock_gettime(CLOCK_MONOTONIC, &c1); jb->t_begin = (double)c1.tv_sec + 1e-9 * (double)c1.tv_nsec; } /* timed runs: all threads leave the gate together */
     for (int rep = 0; rep < jb->reps; ++rep)
     for (size_t ipt = jb->low; ipt < jb->up; ++ipt) {
         uint32_t j = (uint32_t)(ipt / p->width), i = (uint32_t)(ipt - (size_t)j * p->width);
@@ -1077,6 +1080,10 @@ static void* render_job(void* arg) {
         c3 c = render_pixel(jb->sc, p, i, j, &jb->cnt);
         size_t o = ((size_t)local_row(p, j) * p->width + i) * 3;
         jb->out[o] = c.x; jb->out[o + 1] = c.y; jb->out[o + 2] = c.z;
+    }
+    if (jb->start) {
+        clock_gettime(CLOCK_THREAD_CPUTIME_ID, &c1); jb->cpu_s = (double)(c1.tv_sec - c0.tv_sec) + 1e-9 * (double)(c1.tv_nsec - c0.tv_nsec);
+        clock_gettime(CLOCK_MONOTONIC, &c1); jb->t_end = (double)c1.tv_sec + 1e-9 * (double)c1.tv_nsec;
     }
     return NULL;
 }
@@ -1088,6 +1095,10 @@ const char* nrays_oracle_last_error(void) { return g_err; }
  * follows scene.rs:49-66: contiguous static ranges of parts = npixels/num_threads + 1 pixels. */
 static int oracle_render_impl(const NraysSceneDesc* desc, const NraysRenderParams* params, float* out_rgb,
                               int num_threads, NraysStats* stats, int reps, double* seconds);
+/* CPU seconds of the threads of this thread's last timed call: {sum, min, max} — the static contiguous partition of
+ * scene.rs:61-63 gives every thread the same number of pixels, not the same work. */
+static __thread double g_thread_cpu[3];
+void nrays_oracle_last_thread_cpu(double out[3]) { out[0] = g_thread_cpu[0]; out[1] = g_thread_cpu[1]; out[2] = g_thread_cpu[2]; }
 
 int nrays_oracle_render(const NraysSceneDesc* desc, const NraysRenderParams* params, float* out_rgb,
                         int num_threads, NraysStats* stats) {
@@ -1134,7 +1145,18 @@ static int oracle_render_impl(const NraysSceneDesc* desc, const NraysRenderParam
         for (int t = 0; t < num_threads; ++t) pthread_join(th[t], NULL);
         clock_gettime(CLOCK_MONOTONIC, &t1);
         pthread_barrier_destroy(&gate);
-        *seconds = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+        /* wall time of the threaded region = first thread out of the gate .. last thread done, from the threads' own clocks: the caller
+         * shares the cores with them and may be scheduled long after the gate opened (its own t0 then starts late) */
+        (void)t0; (void)t1;
+        { double b = jobs[0].t_begin, e = jobs[0].t_end;
+          for (int t = 1; t < num_threads; ++t) { if (jobs[t].t_begin < b) b = jobs[t].t_begin; if (jobs[t].t_end > e) e = jobs[t].t_end; }
+          *seconds = e - b; }
+        g_thread_cpu[0] = 0.0; g_thread_cpu[1] = jobs[0].cpu_s; g_thread_cpu[2] = jobs[0].cpu_s;
+        for (int t = 0; t < num_threads; ++t) {
+            g_thread_cpu[0] += jobs[t].cpu_s;
+            if (jobs[t].cpu_s < g_thread_cpu[1]) g_thread_cpu[1] = jobs[t].cpu_s;
+            if (jobs[t].cpu_s > g_thread_cpu[2]) g_thread_cpu[2] = jobs[t].cpu_s;
+        }
     } else if (num_threads == 1) render_job(&jobs[0]);
     else {
         for (int t = 0; t < num_threads; ++t) pthread_create(&th[t], NULL, render_job, &jobs[t]);

@@ -7,6 +7,7 @@ nrays_amd.tiling.FramePipeline, comes on top).  Prints one JSON line per workloa
   python tools/tile_scaling.py [balls|sponza8_4k|all]
 """
 import ctypes as C, json, os, sys
+os.environ.setdefault("NRAYS_EVENT_STRIDE", "1")  # HIP events on every frame of a handle (read when the handle is created)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import torch
 import nrays_amd as nr
@@ -17,11 +18,11 @@ lib = abi.load_hip_lib()
 
 
 def rank_ms(sc, full, rank, world, steps):
-    p = tiling.tile_params(full, rank, world, tiling.DEFAULT_BAND_ROWS)
+    p = tiling.tile_params(full, rank, world, int(os.environ.get("BAND_ROWS", tiling.DEFAULT_BAND_ROWS)))
     rows = lib.nrays_tile_rows(C.byref(p))
     out = torch.empty((rows, full.width, 3), dtype=torch.float32, device="cuda")
     h = sc.device_handle()
-    for _ in range(3):
+    for _ in range(int(os.environ.get("SETTLE", "5"))):  # the per-camera scheduling state of a handle settles in three plain frames
         abi.check(lib.nrays_render_device(h, C.byref(p), C.c_void_p(out.data_ptr()), None))
     nr.get_stats(sc)
     for _ in range(steps):
@@ -31,14 +32,16 @@ def rank_ms(sc, full, rank, world, steps):
 
 def run(name, sc, cam, w, h, steps):
     full, _ = su.camera_params(cam, w, h)
-    res = {"workload": name, "res": [w, h]}
+    res = {"workload": name, "res": [w, h], "band_rows": int(os.environ.get("BAND_ROWS", tiling.DEFAULT_BAND_ROWS))}
     t1 = None
-    for world in (1, 2, 4, 8):
+    for world in [int(x) for x in os.environ.get("WORLDS", "1,2,4,8").split(",")]:
         ts = [rank_ms(sc, full, r, world, steps) for r in range(world)]
         if world == 1:
             t1 = ts[0]
-        res["N=%d" % world] = {"slowest_rank_ms": round(max(ts), 4), "fastest_rank_ms": round(min(ts), 4),
-                               "render_speedup_bound": round(t1 / max(ts), 2)}
+        if t1 is None:
+            t1 = float(os.environ.get("T1_MS", "0")) or sum(ts)
+        res["N=%d" % world] = {"slowest_rank_ms": round(max(ts), 4), "fastest_rank_ms": round(min(ts), 4), "mean_rank_ms": round(sum(ts) / len(ts), 4),
+                               "render_speedup_bound": round(t1 / max(ts), 2), "rank_ms": [round(t, 3) for t in ts]}
     print(json.dumps(res), flush=True)
 
 
