@@ -488,8 +488,11 @@ __global__ void __launch_bounds__(kBlock, NRAYS_WAVES_PER_SIMD) k_bounce(DScene 
     flush_counters(ctr, cnt, STATS);
 }
 
+// (FEAT: kFeatAll, or kFeatMesh for scenes of opaque TriMesh nodes only — the permutation whose node phases end by quorum in
+// hair-like meshes, so that the independent fixtures also cover that path.)
 // nrays_debug_cast_batch: the closest-hit query with the deferred exact gates exactly as shade_hit runs it (ungated traversal, the
 // winner checked against the reference's AABB gates, fully gated repeat for knife-edge rays), or the shadow query, on rays from memory.
+template <int FEAT>
 __global__ void __launch_bounds__(kBlock, NRAYS_WAVES_PER_SIMD) k_cast_batch(DScene S, uint32_t mode, uint32_t n, const double* __restrict__ ro, const double* __restrict__ rd,
                                                                               const double* __restrict__ max_toi, NraysCastResult* __restrict__ out, uint32_t* spill) {
     __shared__ uint32_t lds_stack[kLdsStack * kBlock];
@@ -510,14 +513,14 @@ __global__ void __launch_bounds__(kBlock, NRAYS_WAVES_PER_SIMD) k_cast_batch(DSc
         NraysCastResult r; r.toi = 0.0; r.normal[0] = r.normal[1] = r.normal[2] = 0.0; r.uv[0] = r.uv[1] = 0.0; r.node_id = -1; r.flags = 0u;
         Hit hit; f3 filter = F3(1.0f, 1.0f, 1.0f);
         if (mode == 1u) {
-            const bool blocked = traverse<true, false, kFeatAll>(S, st, o, d, max_toi[i], hit, filter, cnt);
+            const bool blocked = traverse<true, false, FEAT>(S, st, o, d, max_toi[i], hit, filter, cnt);
             r.flags = blocked ? 1u : 0u; r.normal[0] = filter.x; r.normal[1] = filter.y; r.normal[2] = filter.z;
         } else {
             Isect is; uint32_t node_id = 0; bool gated = false, any = false;
             for (;;) {
-                any = traverse<false, false, kFeatAll>(S, st, o, d, kDblMax, hit, filter, cnt, gated, &is);
+                any = traverse<false, false, FEAT>(S, st, o, d, kDblMax, hit, filter, cnt, gated, &is);
                 if (!any) break;
-                if (resolve_hit<false, kFeatAll, true>(S, o, d, hit, is, node_id) || gated) break;
+                if (resolve_hit<false, FEAT, true>(S, o, d, hit, is, node_id) || gated) break;
                 gated = true;
             }
             if (any) {
@@ -590,28 +593,31 @@ __global__ void __launch_bounds__(1024) k_tile_order(const uint32_t* __restrict_
 // mirrors (scene.rs:204).  cost = 1 + 4 x (boxes of such nodes the ray through the tile's centre pixel crosses), f32 slab tests against
 // their world AABBs: a few microseconds, and k_tile_order then starts those tiles first, as it does from recorded costs on later
 // frames.  Scheduling only: pixels do not depend on it.
-__global__ void k_seed_costs(DRender R, const float* __restrict__ boxes, uint32_t nboxes, uint32_t* __restrict__ cost, uint32_t nwt) {
+__global__ void k_seed_costs(DRender R, const float* __restrict__ boxes, uint32_t nboxes, uint32_t* __restrict__ cost, uint32_t nwt, uint32_t nrays) {
     const uint32_t wt = blockIdx.x * blockDim.x + threadIdx.x;
     if (wt >= nwt) return;
     const uint32_t tile = wt >> 2, sub = wt & 3u;
     const uint32_t tx = R.win_x0 + tile % R.win_nx, ty = R.win_y0 + tile / R.win_nx;
-    const uint32_t i = tx * kTile + ((sub & 1u) << 3) + 4u, rl = ty * kTile + ((sub >> 1) << 3) + 4u;
-    uint32_t j = rl;
-    if (R.band_rows != 0 && R.band_owners > 1) j = ((rl / R.band_rows) * R.band_owners + R.band_owner) * R.band_rows + (rl % R.band_rows);
-    const double dx = ((double)i / (double)R.width - 0.5) * 2.0, dy = -((double)j / (double)R.height - 0.5) * 2.0;
-    double h[4];
-    for (int r = 0; r < 4; ++r) h[r] = R.m[r] * dx + R.m[4 + r] * dy - R.m[8 + r] + R.m[12 + r];
-    const float ox = (float)R.eye[0], oy = (float)R.eye[1], oz = (float)R.eye[2];
-    const float ix = 1.0f / (float)(h[0] / h[3] - R.eye[0]), iy = 1.0f / (float)(h[1] / h[3] - R.eye[1]), iz = 1.0f / (float)(h[2] / h[3] - R.eye[2]);
     uint32_t n = 0u;
-    for (uint32_t b = 0; b < nboxes; ++b) {
-        const float* q = boxes + 6u * b;
-        float t0 = (q[0] - ox) * ix, t1 = (q[3] - ox) * ix; float lo = fminf(t0, t1), hi = fmaxf(t0, t1);
-        t0 = (q[1] - oy) * iy; t1 = (q[4] - oy) * iy; lo = fmaxf(lo, fminf(t0, t1)); hi = fminf(hi, fmaxf(t0, t1));
-        t0 = (q[2] - oz) * iz; t1 = (q[5] - oz) * iz; lo = fmaxf(lo, fminf(t0, t1)); hi = fminf(hi, fmaxf(t0, t1));
-        n += (hi >= fmaxf(lo, 0.0f)) ? 1u : 0u;
+    for (uint32_t q = 0; q < nrays; ++q) { // the tile's centre pixel, or the centres of its four quadrants
+        const uint32_t px = nrays == 1u ? 4u : 2u + 4u * (q & 1u), py = nrays == 1u ? 4u : 2u + 4u * (q >> 1);
+        const uint32_t i = tx * kTile + ((sub & 1u) << 3) + px, rl = ty * kTile + ((sub >> 1) << 3) + py;
+        uint32_t j = rl;
+        if (R.band_rows != 0 && R.band_owners > 1) j = ((rl / R.band_rows) * R.band_owners + R.band_owner) * R.band_rows + (rl % R.band_rows);
+        const double dx = ((double)i / (double)R.width - 0.5) * 2.0, dy = -((double)j / (double)R.height - 0.5) * 2.0;
+        double h[4];
+        for (int r = 0; r < 4; ++r) h[r] = R.m[r] * dx + R.m[4 + r] * dy - R.m[8 + r] + R.m[12 + r];
+        const float ox = (float)R.eye[0], oy = (float)R.eye[1], oz = (float)R.eye[2];
+        const float ix = 1.0f / (float)(h[0] / h[3] - R.eye[0]), iy = 1.0f / (float)(h[1] / h[3] - R.eye[1]), iz = 1.0f / (float)(h[2] / h[3] - R.eye[2]);
+        for (uint32_t b = 0; b < nboxes; ++b) {
+            const float* bx = boxes + 6u * b;
+            float t0 = (bx[0] - ox) * ix, t1 = (bx[3] - ox) * ix; float lo = fminf(t0, t1), hi = fmaxf(t0, t1);
+            t0 = (bx[1] - oy) * iy; t1 = (bx[4] - oy) * iy; lo = fmaxf(lo, fminf(t0, t1)); hi = fminf(hi, fmaxf(t0, t1));
+            t0 = (bx[2] - oz) * iz; t1 = (bx[5] - oz) * iz; lo = fmaxf(lo, fminf(t0, t1)); hi = fminf(hi, fmaxf(t0, t1));
+            n += (hi >= fmaxf(lo, 0.0f)) ? 1u : 0u;
+        }
     }
-    cost[wt] = 1u + 4u * n;
+    cost[wt] = 1u + (nrays == 1u ? 4u : 1u) * n;
 }
 
 // Screen bounds of the scene for one camera: the pixel rectangle outside of which no primary ray can reach the scene's
@@ -1034,7 +1040,7 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
             const bool seeded = !(sc->cost_valid && sc->cost_key == key) && sc->seed_enabled && sc->seed_boxes != 0u && lane_log2 == 0u && win_units > 0;
             if (seeded) {
                 if (timed) HIP_TRY(hipEventRecord(sc->ev_begin[slot], stream));
-                hipLaunchKernelGGL(k_seed_costs, dim3((nwt + 255u) / 256u), dim3(256), 0, stream, R, (const float*)sc->d_seed_boxes, sc->seed_boxes, sc->d_tile_cost, nwt);
+                hipLaunchKernelGGL(k_seed_costs, dim3((nwt + 255u) / 256u), dim3(256), 0, stream, R, (const float*)sc->d_seed_boxes, sc->seed_boxes, sc->d_tile_cost, nwt, sc->seed_rays);
                 HIP_TRY(hipGetLastError());
             }
             if (seeded || (sc->cost_valid && sc->cost_key == key)) {
@@ -1312,7 +1318,7 @@ int nrays_scene_create(const NraysSceneDesc* desc, NraysScene** out_scene) {
         const float* dptr = nullptr;
         if ((rc = upload(sc, boxes, &dptr)) != NRAYS_OK) return bail(rc);
         sc->d_seed_boxes = dptr; sc->seed_boxes = (uint32_t)(boxes.size() / 6);
-        if (const char* e = getenv("NRAYS_COST_SEED")) sc->seed_enabled = atoi(e) != 0;
+        if (const char* e = getenv("NRAYS_COST_SEED")) { sc->seed_enabled = atoi(e) != 0; if (atoi(e) == 4) sc->seed_rays = 4u; if (atoi(e) == 1) sc->seed_rays = 1u; }
     }
     if (const char* e = getenv("NRAYS_MAX_PRIMARY")) { sc->max_primary_per_launch = (uint64_t)std::max(1ll, atoll(e)); sc->max_primary_forced = true; }
     if (const char* e = getenv("NRAYS_LANE_LOG2")) sc->lane_log2_override = std::max(0, std::min(6, atoi(e)));
@@ -1586,7 +1592,8 @@ int nrays_debug_cast_batch(NraysScene* sc, uint32_t mode, uint32_t n, const doub
     CAST_TRY(hipMemcpy(d_o, origins, vb, hipMemcpyHostToDevice)); CAST_TRY(hipMemcpy(d_d, dirs, vb, hipMemcpyHostToDevice));
     if (mode == 1u) { CAST_TRY(hipMalloc((void**)&d_t, (size_t)n * sizeof(double))); CAST_TRY(hipMemcpy(d_t, max_toi, (size_t)n * sizeof(double), hipMemcpyHostToDevice)); }
     const uint32_t grid = std::min<uint32_t>((n + kBlock - 1) / kBlock, (uint32_t)kMaxGrid);
-    hipLaunchKernelGGL(k_cast_batch, dim3(grid), dim3(kBlock), 0, sc->own_stream, sc->d, mode, n, d_o, d_d, d_t, d_r, sc->d_spill);
+    if ((sc->features & ~(int)kFeatMultiSample) == (int)kFeatMesh) hipLaunchKernelGGL((k_cast_batch<kFeatMesh>), dim3(grid), dim3(kBlock), 0, sc->own_stream, sc->d, mode, n, d_o, d_d, d_t, d_r, sc->d_spill);
+    else hipLaunchKernelGGL((k_cast_batch<kFeatAll>), dim3(grid), dim3(kBlock), 0, sc->own_stream, sc->d, mode, n, d_o, d_d, d_t, d_r, sc->d_spill);
     CAST_TRY(hipGetLastError());
     CAST_TRY(hipStreamSynchronize(sc->own_stream));
     CAST_TRY(hipMemcpy(out, d_r, (size_t)n * sizeof(NraysCastResult), hipMemcpyDeviceToHost));

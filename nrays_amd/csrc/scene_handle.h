@@ -51,7 +51,7 @@ struct NraysScene {
     // light-parallel tiles: log2 of the lanes per pixel (0 = the scene is not eligible), the split threshold in units of the frame's
     // work per resident wave (NRAYS_LIGHT_SPLIT: 0 = never, < 0 = every tile, default 1), the lengths of the eight lists
     uint32_t light_lsl = 0; float light_split_factor = 1.0f; uint32_t* d_order_len = nullptr;
-    const float* d_seed_boxes = nullptr; uint32_t seed_boxes = 0; bool seed_enabled = true; // k_seed_costs: first guess of a cold camera's tile costs (NRAYS_COST_SEED=0: none)
+    const float* d_seed_boxes = nullptr; uint32_t seed_boxes = 0; bool seed_enabled = true; uint32_t seed_rays = 1; // k_seed_costs: first guess of a cold camera's tile costs (NRAYS_COST_SEED=0: none)
     uint64_t cost_key = 0; bool cost_valid = false;
     uint32_t cost_tiles = 0, cost_grid = 0; // wave tiles / workgroups of the frame that recorded d_tile_cost last (nrays_get_tile_costs)
     // analytic scenes (workgroup lists): costs are recorded on the first frame of a camera, sorted once on the second, and

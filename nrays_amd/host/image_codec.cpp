@@ -70,6 +70,7 @@ Image8 read_tga(const std::vector<uint8_t>& d, const std::string& path) {
     size_t pos = 18 + (size_t)idlen;
     std::vector<uint8_t> palette;
     if (cmap) {
+        if (cm_len == 0) throw std::runtime_error("tga: colour-mapped image without a colour map: " + path);
         const size_t eb = (size_t)(cm_bits + 7) / 8;
         if (pos + eb * cm_len > d.size()) throw std::runtime_error("tga: truncated colour map: " + path);
         palette.resize((size_t)cm_len * comp);
@@ -77,6 +78,9 @@ Image8 read_tga(const std::vector<uint8_t>& d, const std::string& path) {
         pos += eb * cm_len;
     } else if (cm_len) pos += (size_t)((cm_bits + 7) / 8) * cm_len; // a colour map an unmapped image does not use
     const size_t pb = (size_t)(bpp + 7) / 8;  // stored bytes per pixel (the index for colour-mapped images)
+    // every pixel takes at least one stored byte (a run-length packet of 1 + pb bytes covers at most 128): a header that promises more
+    // pixels than the file can hold is rejected BEFORE the output is allocated
+    if ((uint64_t)w * h > (uint64_t)(d.size() - std::min(pos, d.size())) * 128u) throw std::runtime_error("tga: truncated pixel data: " + path);
     Image8 out; out.width = w; out.height = h; out.channels = comp; out.data.resize((size_t)w * h * comp);
     uint8_t px[4] = {0, 0, 0, 0};
     auto fetch = [&]() {
@@ -324,6 +328,7 @@ struct JDec {
     }
     void scan(size_t p, size_t end) {
         if (!width) fail("scan before the frame header");
+        if (p >= end) fail("bad scan header");
         const int ns = d[p];
         if (ns < 1 || ns > (int)comps.size() || p + 1 + 2 * (size_t)ns + 3 > end) fail("bad scan header");
         std::vector<JComp*> sc;

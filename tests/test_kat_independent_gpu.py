@@ -59,6 +59,25 @@ def test_hip_casts_equal_the_oracle_bit_for_bit_on_random_scenes(gpu):
     assert h > 100 and u > 50
 
 
+def test_hip_casts_through_a_hair_mesh_equal_the_oracle(gpu):
+    """Scenes of opaque TriMesh nodes only are probed with the opaque-mesh permutation of the traversal (k_cast_batch<kFeatMesh>): in a
+    hair-like mesh its node phases end by quorum and the parked lanes resume later (trace_device.h: traverse, DScene::incoherent) —
+    hit / miss, node and toi of random rays through the hairball stand-in must still be the oracle's, bit for bit."""
+    import ctypes as C
+    from nrays_amd import abi
+    from tools import standins
+    sc, _ = standins.hairball_scene(strands=400)
+    flags = (C.c_uint32 * 2)()
+    abi.check(abi.load_hip_lib().nrays_debug_scene_flags(sc.device_handle(), flags))
+    assert flags[0] == 2 and flags[1] == 1, tuple(flags)  # opaque meshes only, hair-like: the quorum path
+    rng = np.random.default_rng(23)
+    o = rng.normal(size=(6000, 3)); o *= 3.0 / np.linalg.norm(o, axis=1, keepdims=True)
+    t = rng.normal(size=(6000, 3)) * 0.12 + np.array([0.0, 0.1, 0.0])
+    d = t - o; d /= np.linalg.norm(d, axis=1, keepdims=True)
+    h, _ = _same_casts(sc, o, d)
+    assert h > 1500
+
+
 def test_hip_shadow_queries_equal_the_oracle(gpu):
     """Scene::intersects_ray on the device alone: blocked / lit identical, the colour filter of the transparent nodes
     crossed equal up to the order of its f32 products."""
