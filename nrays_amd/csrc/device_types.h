@@ -252,7 +252,13 @@ enum Features : int {
     kFeatMultiSample = 16, // more than one light sample per hit: shadow rays are traced inside the light loop;
                            // otherwise the single shadow ray is traced before the shading state exists
     kFeatAll = 31,
-    kFeatLdsScene = 32     // analytic-only scenes whose records fit DScene::lds_blob: the kernel reads them from LDS
+    kFeatLdsScene = 32,    // analytic-only scenes whose records fit DScene::lds_blob: the kernel reads them from LDS
+    kFeatNoXform = 64,     // every TLAS leaf is an untransformed BLAS (identity rotation, zero translation: local space == world space):
+                           // the traversal keeps ONE ray instead of a world and a local one — 12 VGPRs and the two ray set-ups per BLAS
+                           // visit (the three-wave multi-light kernel: 170 -> 123 spilled dwords, config 4 12.5 -> 11.3 ms)
+    kFeatPark = 128        // the three-wave multi-light permutations park a hit's shading state (normal, point, ray direction: 18 dwords
+                           // per lane) in LDS across each of its shadow traversals, so that it does not sit in — or get spilled around —
+                           // the traversal's inner loops (Stack::park; trace_device.h: material_compute)
 };
 
 } // namespace nrays

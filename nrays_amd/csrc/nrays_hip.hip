@@ -134,7 +134,7 @@ __device__ __forceinline__ void flush_counters(DeviceCounters* ctr, const Cnt& c
 #ifndef NR_OPAQUE_MESH_WAVES
 #define NR_OPAQUE_MESH_WAVES 4
 #endif
-constexpr int waves_per_simd(int feat) { return (feat & ~(kFeatMultiSample | kFeatLdsScene)) == kFeatMesh ? (NRAYS_WAVES_PER_SIMD > NR_OPAQUE_MESH_WAVES ? NRAYS_WAVES_PER_SIMD : NR_OPAQUE_MESH_WAVES) : NRAYS_WAVES_PER_SIMD; }
+constexpr int waves_per_simd(int feat) { return (feat & ~(kFeatMultiSample | kFeatLdsScene | kFeatNoXform | kFeatPark)) == kFeatMesh ? (NRAYS_WAVES_PER_SIMD > NR_OPAQUE_MESH_WAVES ? NRAYS_WAVES_PER_SIMD : NR_OPAQUE_MESH_WAVES) : NRAYS_WAVES_PER_SIMD; }
 
 // OCC != 0: the alpha-shadow mesh permutations also exist at three waves per SIMD (168 VGPRs, ~64 dwords of scratch per lane): a
 // wave then runs slower, which lengthens a frame that is as long as its longest tile (sponza 1080p: 1.40 -> 1.67 ms) and shortens a
@@ -180,11 +180,14 @@ __global__ void __launch_bounds__(kBlock, OCC ? OCC : waves_per_simd(FEAT)) k_pr
         if (threadIdx.x < kNumCounts) zero_counts[threadIdx.x] = 0u;
         if (zero_ctr && threadIdx.x < sizeof(DeviceCounters) / 4) ((uint32_t*)zero_ctr)[threadIdx.x] = 0u;
     }
+    constexpr bool kPark = (FEAT & kFeatPark) != 0;
+    __shared__ uint32_t lds_park[kPark ? park_slots(FEAT) * kBlock : 4];
     Stack st;
     st.lds = (lds_u32*)(lds_stack + threadIdx.x);
     st.spill_stride = gridDim.x * kBlock;
     st.spill = spill ? (global_u32*)(spill + (size_t)blockIdx.x * kBlock + threadIdx.x) : nullptr;
     st.lds0 = Stack::addr((lds_u32*)lds_stack);
+    st.park = (lds_u32*)(lds_park + threadIdx.x);
     st.init();
     Cnt cnt; cnt.node = cnt.tri = cnt.prim = cnt.hit = cnt.tex = cnt.shadow = cnt.refl = cnt.refr = cnt.max_depth = cnt.max_chain_nodes = cnt.traced = 0;
 #ifdef NR_PHASE_TIMING
@@ -461,6 +464,7 @@ __global__ void __launch_bounds__(kBlock, NRAYS_WAVES_PER_SIMD) k_bounce(DScene 
     st.spill_stride = gridDim.x * kBlock;
     st.spill = spill ? (global_u32*)(spill + (size_t)blockIdx.x * kBlock + threadIdx.x) : nullptr;
     st.lds0 = Stack::addr((lds_u32*)lds_stack);
+    st.park = nullptr;
     st.init();
     Cnt cnt; cnt.node = cnt.tri = cnt.prim = cnt.hit = cnt.tex = cnt.shadow = cnt.refl = cnt.refr = cnt.max_depth = cnt.max_chain_nodes = cnt.traced = 0;
 #ifdef NR_PHASE_TIMING
@@ -501,6 +505,7 @@ __global__ void __launch_bounds__(kBlock, NRAYS_WAVES_PER_SIMD) k_cast_batch(DSc
     st.spill_stride = gridDim.x * kBlock;
     st.spill = spill ? (global_u32*)(spill + (size_t)blockIdx.x * kBlock + threadIdx.x) : nullptr;
     st.lds0 = Stack::addr((lds_u32*)lds_stack);
+    st.park = nullptr;
     st.init();
     Cnt cnt; cnt.node = cnt.tri = cnt.prim = cnt.hit = cnt.tex = cnt.shadow = cnt.refl = cnt.refr = cnt.max_depth = cnt.max_chain_nodes = cnt.traced = 0;
 #ifdef NR_PHASE_TIMING
@@ -799,7 +804,7 @@ static uint32_t tile_rows(const NraysRenderParams* p) {
 
 // The primary kernel is instantiated per feature set; instrumented renders and k_bounce use the
 // full-featured code (their results are identical, only slower).
-static void launch_primary(bool instrumented, int features, int occ, uint32_t grid, hipStream_t stream, const DScene& d, const DRender& R,
+static void launch_primary(bool instrumented, int features, bool noxform, bool park, int occ, uint32_t grid, hipStream_t stream, const DScene& d, const DRender& R,
                            const QueueOut& qo, float* out, DeviceCounters* ctr, uint32_t* spill, uint32_t tx, uint32_t ty, uint32_t* work, uint32_t grab,
                            uint32_t* zero_counts, DeviceCounters* zero_ctr) {
 #define NR_LAUNCH(F) hipLaunchKernelGGL((k_primary<false, F>), dim3(grid), dim3(kBlock), 0, stream, d, R, qo, out, ctr, spill, tx, ty, work, grab, zero_counts, zero_ctr)
@@ -809,9 +814,14 @@ static void launch_primary(bool instrumented, int features, int occ, uint32_t gr
 #define NR_LAUNCH_PLAIN(F) hipLaunchKernelGGL((k_primary<false, F, true>), dim3(grid), dim3(kBlock), 0, stream, d, R, qo, out, ctr, spill, tx, ty, work, grab, zero_counts, zero_ctr)
     if (occ == 3) { // the three-wave builds of the alpha-shadow mesh permutations
 #define NR_LAUNCH_OCC3(F, P) hipLaunchKernelGGL((k_primary<false, F, P, 3>), dim3(grid), dim3(kBlock), 0, stream, d, R, qo, out, ctr, spill, tx, ty, work, grab, zero_counts, zero_ctr)
+        if (noxform) switch (features) { // every BLAS untransformed (kFeatNoXform)
+        case 6: if (park) { if (plain) NR_LAUNCH_OCC3(198, true); else NR_LAUNCH_OCC3(198, false); } else { if (plain) NR_LAUNCH_OCC3(70, true); else NR_LAUNCH_OCC3(70, false); } return;
+        case 22: if (park) { if (plain) NR_LAUNCH_OCC3(214, true); else NR_LAUNCH_OCC3(214, false); } else { if (plain) NR_LAUNCH_OCC3(86, true); else NR_LAUNCH_OCC3(86, false); } return;
+        default: break;
+        }
         switch (features) {
-        case 6: if (plain) NR_LAUNCH_OCC3(6, true); else NR_LAUNCH_OCC3(6, false); return;
-        case 22: if (plain) NR_LAUNCH_OCC3(22, true); else NR_LAUNCH_OCC3(22, false); return;
+        case 6: if (park) { if (plain) NR_LAUNCH_OCC3(134, true); else NR_LAUNCH_OCC3(134, false); } else { if (plain) NR_LAUNCH_OCC3(6, true); else NR_LAUNCH_OCC3(6, false); } return;
+        case 22: if (park) { if (plain) NR_LAUNCH_OCC3(150, true); else NR_LAUNCH_OCC3(150, false); } else { if (plain) NR_LAUNCH_OCC3(22, true); else NR_LAUNCH_OCC3(22, false); } return;
 #ifndef NR_ONLY_MESH
         case 7: NR_LAUNCH_OCC3(7, false); return;
         case 23: NR_LAUNCH_OCC3(23, false); return;
@@ -830,6 +840,21 @@ static void launch_primary(bool instrumented, int features, int occ, uint32_t gr
     if (plain && features == 17) { NR_LAUNCH_PLAIN(17); return; }
     if (plain && features == 21) { NR_LAUNCH_PLAIN(21); return; }
 #endif
+    if (noxform) { // mesh-only scenes whose BLASes are all untransformed: the kFeatNoXform permutations
+        if (plain) switch (features) {
+            case 2: NR_LAUNCH_PLAIN(66); return;
+            case 6: NR_LAUNCH_PLAIN(70); return;
+            case 18: NR_LAUNCH_PLAIN(82); return;
+            case 22: NR_LAUNCH_PLAIN(86); return;
+            default: break;
+        } else switch (features) {
+            case 2: NR_LAUNCH(66); return;
+            case 6: NR_LAUNCH(70); return;
+            case 18: NR_LAUNCH(82); return;
+            case 22: NR_LAUNCH(86); return;
+            default: break;
+        }
+    }
     if (plain && features == 2) { NR_LAUNCH_PLAIN(2); return; }
     if (plain && features == 6) { NR_LAUNCH_PLAIN(6); return; }
     if (plain && features == 18) { NR_LAUNCH_PLAIN(18); return; }
@@ -1138,7 +1163,7 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
         QueueOut qo; qo.q = sc->queue[1].q; qo.capacity = queued ? sc->queue_capacity : 0; qo.count = sc->d_counts + 1;
         qo.overflow = &sc->d_counters->overflow;
         if (first_primary && timed) HIP_TRY(hipEventRecord(sc->ev_pbegin[slot], stream));
-        launch_primary(instrumented, sc->features, occ, grid_primary, stream, sc->d, R, qo, d_out, sc->d_counters, sc->d_spill, tiles_x, tiles_y, sc->d_counts + kMaxGenerations + 2, grab, next_counts, R.first_batch ? next_ctr : nullptr);
+        launch_primary(instrumented, sc->features, sc->noxform, sc->park, occ, grid_primary, stream, sc->d, R, qo, d_out, sc->d_counters, sc->d_spill, tiles_x, tiles_y, sc->d_counts + kMaxGenerations + 2, grab, next_counts, R.first_batch ? next_ctr : nullptr);
         HIP_TRY(hipGetLastError());
         if (first_primary) {
             if (timed) HIP_TRY(hipEventRecord(sc->ev_pend[slot], stream));
@@ -1272,6 +1297,16 @@ int nrays_scene_create(const NraysSceneDesc* desc, NraysScene** out_scene) {
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, sc->device) == hipSuccess && cus > 0) sc->num_cus = cus;
     }
     sc->features = h.features ? h.features : kFeatAll;
+    {   // kFeatNoXform: scenes of TriMesh nodes only whose BLASes all sit in world space (NRAYS_NOXFORM=0: the general permutations, A/B)
+        const int f = sc->features;
+        bool all = (f == 2 || f == 6 || f == 18 || f == 22) && !h.links.empty();
+        for (const InstLink& l : h.links) all = all && (l.flags & kInstNoXform);
+        for (const InstLink& l : h.shadow_links) all = all && (l.flags & kInstNoXform);
+        const char* e = getenv("NRAYS_NOXFORM");
+        sc->noxform = all && !(e && atoi(e) == 0);
+        const char* pe = getenv("NRAYS_PARK"); // =0: the three-wave multi-light kernels keep a hit's shading state in registers / scratch (A/B)
+        sc->park = !(pe && atoi(pe) == 0);
+    }
     // small analytic scenes: one packed copy of the records for the kernels that read them from LDS (DScene::lds_blob)
     sc->d.lds_blob = nullptr; sc->d.lds_bytes = 0;
     { const char* e = getenv("NRAYS_LDS_SCENE");

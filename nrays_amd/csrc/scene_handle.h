@@ -68,6 +68,8 @@ struct NraysScene {
     uint32_t spill_entries = 0; // HBM stack entries per lane beyond the kLdsStack entries kept in LDS (0 = never needed)
     int num_cus = 256;
     int features = nrays::kFeatAll;
+    bool park = true;     // kFeatPark permutations for the three-wave multi-light kernels (NRAYS_PARK=0: off)
+    bool noxform = false; // every BLAS untransformed: the kFeatNoXform permutations of the mesh kernels render this scene
     float* d_frame = nullptr; size_t frame_floats = 0;
     uint8_t* d_rgb8 = nullptr; size_t rgb8_bytes = 0; // nrays_render_rgb8
     hipStream_t own_stream = nullptr;

@@ -29,10 +29,15 @@ namespace nrays {
 
 constexpr int kBlock = 256;     // threads per workgroup = 4 wave64 (8-wave workgroups measured slower: 100 vs 86 us on balls)
 #ifndef NR_LDS_STACK
-#define NR_LDS_STACK 32
+#define NR_LDS_STACK 24 // (32 until round 4: no measurable difference on any scene, profiles/r04_register_relief_ab.log; the LDS it frees holds Stack::park)
 #endif
 constexpr int kLdsStack = NR_LDS_STACK;   // traversal-stack entries kept in LDS per lane (then spills to HBM)
 constexpr int32_t kSentinel = (int32_t)0x80000001; // marks "leave the BLAS" on the traversal stack
+// Stack::park: dwords per lane a kFeatPark permutation keeps in LDS — what fits beside the traversal stacks of its resident workgroups
+// (160 KiB per CU; three workgroups of 24 KiB of stack + 25 KiB: with 29 dwords a third workgroup no longer fitted and config 4 went from
+// 10.8 to 14.9 ms): the three-wave alpha-shadow kernels 25 (several lights) / 24 (one light).  The four-wave opaque-mesh kernel gains
+// nothing from 14 parked dwords (hairball 2.02 ms either way, 16 spp 19.0 -> 19.2): it has no kFeatPark permutation.
+constexpr int park_slots(int feat) { return !(feat & kFeatPark) ? 0 : ((feat & kFeatMultiSample) ? 25 : 24); }
 constexpr int32_t kParked = (int32_t)0x80000002;   // a lane that yielded its node phase (traverse(): node_quorum); like kEmptyChild / kSentinel not a leaf ref
                                                    // that can occur (first = 2^28 - 1: scene_build.cpp refuses scenes that large)
 
@@ -125,6 +130,21 @@ struct Stack {
     global_u32* spill; // &spill[global lane]   (may be null when the tree depth fits in LDS)
     uint32_t spill_stride;
     uint32_t lds0;     // uniform: LDS address of lds_stack[0]
+    lds_u32* park;     // kFeatPark kernels: &lds_park[threadIdx.x], kParkSlots dwords per lane laid out [slot][lane] like the stack
+    NR_DEV void park_d3(int slot, d3 v) const {
+        volatile lds_u32* p = park + slot * kBlock;
+        p[0] = (uint32_t)__double2loint(v.x); p[kBlock] = (uint32_t)__double2hiint(v.x); p[2 * kBlock] = (uint32_t)__double2loint(v.y);
+        p[3 * kBlock] = (uint32_t)__double2hiint(v.y); p[4 * kBlock] = (uint32_t)__double2loint(v.z); p[5 * kBlock] = (uint32_t)__double2hiint(v.z);
+    }
+    NR_DEV void park_f(int slot, float v) const { *(volatile lds_u32*)(park + slot * kBlock) = __float_as_uint(v); }
+    NR_DEV float unpark_f(int slot) const { return __uint_as_float(*(volatile lds_u32*)(park + slot * kBlock)); }
+    NR_DEV void park_d(int slot, double v) const { volatile lds_u32* p = park + slot * kBlock; p[0] = (uint32_t)__double2loint(v); p[kBlock] = (uint32_t)__double2hiint(v); }
+    NR_DEV double unpark_d(int slot) const { volatile lds_u32* p = park + slot * kBlock; const uint32_t a = p[0], b = p[kBlock]; return __hiloint2double((int)b, (int)a); }
+    NR_DEV d3 unpark_d3(int slot) const {
+        volatile lds_u32* p = park + slot * kBlock;
+        const uint32_t a = p[0], b = p[kBlock], c = p[2 * kBlock], d = p[3 * kBlock], e = p[4 * kBlock], f = p[5 * kBlock];
+        return D3(__hiloint2double((int)b, (int)a), __hiloint2double((int)d, (int)c), __hiloint2double((int)f, (int)e));
+    }
     NR_DEV static uint32_t addr(const lds_u32* p) { return (uint32_t)(uintptr_t)p; }
     NR_DEV void init() { lds[0] = (uint32_t)kEmptyChild; top = lds + kBlock; } // once per kernel: nothing ever overwrites slot 0
     NR_DEV void reset() { top = lds + kBlock; }
@@ -796,16 +816,20 @@ NR_DEV bool resolve_hit(const DScene& S, d3 o, d3 d, const Hit& h, Isect& out, u
         return !CHECK || in.kind == NRAYS_SHAPE_PLANE || node_aabb_pass(S, node_id, o, d);
     }
     if (!(FEAT & kFeatMesh)) { node_id = 0; out.toi = 0.0; out.n = D3(0, 0, 0); out.u = out.v = 0.0; out.has_uv = false; return true; }
-    Xform m; load_xform(in, m);
+    Xform m;
     d3 lo = o, ld = d;
-    if (!(in.flags & kInstIdentityRot)) { lo = inv_rot(m, o - m.t); ld = inv_rot(m, d); }
-    else lo = o - m.t;
+    constexpr bool kNoXf = (FEAT & kFeatNoXform) != 0;
+    if (!kNoXf) {
+        load_xform(in, m);
+        if (!(in.flags & kInstIdentityRot)) { lo = inv_rot(m, o - m.t); ld = inv_rot(m, d); }
+        else lo = o - m.t;
+    }
     const TriRec& tr = S.tris[h.prim];
     d3 a = D3(tr.v0[0], tr.v0[1], tr.v0[2]), b = D3(tr.v1[0], tr.v1[1], tr.v1[2]), c = D3(tr.v2[0], tr.v2[1], tr.v2[2]);
     double bary[3]; d3 n; double toi;
     cast_triangle(a, b, c, lo, ld, toi, &n, bary);
     out.toi = toi;
-    out.n = (in.flags & kInstIdentityRot) ? n : rot(m, n);
+    out.n = (kNoXf || (in.flags & kInstIdentityRot)) ? n : rot(m, n);
     node_id = tr.node_id;
     out.has_uv = (S.shade[node_id].flags & 1u) != 0;
     out.u = 0.0; out.v = 0.0;
@@ -857,6 +881,7 @@ NR_DEV bool traverse(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, Hit&
     constexpr bool kAlpha = (FEAT & kFeatAlphaShadow) != 0; // shadow mode: otherwise every hit within tlimit blocks
     // the opaque-mesh kernels only (where hair lives): the three scalar instructions per visit cost the alpha-shadow kernels 2 %
     constexpr bool kQuorum = NR_NODE_QUORUM_DEN != 0 && kMesh && !kAnalytic && !kAlpha;
+    constexpr bool kNoXf = (FEAT & kFeatNoXform) != 0; // no instance moves the ray: co / cd stay o / d (the compiler then keeps one copy)
     const Instance* insts = SHADOW ? S.shadow_instances : S.instances;
     const InstLink* links = SHADOW ? S.shadow_links : S.links;
     double bt = SHADOW ? tlimit : kDblMax;
@@ -967,7 +992,7 @@ NR_DEV bool traverse(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, Hit&
         if (cur == kEmptyChild) break;
         if (kMesh && cur == kSentinel) { // the BLAS of `cur_inst` is exhausted: back to world space
             in_blas = false;
-            if (!(cur_flags & kInstNoXform)) { co = o; cd = d; rf = make_rayf(o, d); }
+            if (!kNoXf && !(cur_flags & kInstNoXform)) { co = o; cd = d; rf = make_rayf(o, d); }
             if (SHADOW && kAlpha && !(cur_flags & kInstAnyHit)) {
                 if (bhit) {
                     Hit h; h.t = bt; h.inst = cur_inst; h.prim = bprim;
@@ -1015,7 +1040,7 @@ NR_DEV bool traverse(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, Hit&
             cur_inst = first;
             InstLink link = links[first];
             cur_flags = link.flags;
-            if (!(bits & kLeafNoXform)) { // rotated / translated instance: move the ray into its local frame
+            if (!kNoXf && !(bits & kLeafNoXform)) { // rotated / translated instance: move the ray into its local frame
                 const Instance& in = insts[first];
                 Xform m; load_xform(in, m);
                 if (in.flags & kInstIdentityRot) { co = o - m.t; cd = d; }
@@ -1090,7 +1115,7 @@ NR_DEV bool shadow_query(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, 
 // then folded into `res` in light order by every lane of the group (`__shfl` from the lane that holds light l), i.e. exactly
 // `res = res + acc_l / n_l` light after light (phong_material.rs:106-147): the pixel is bit-identical to the one-lane loop.
 template <bool STATS, int FEAT>
-NR_MAT_ATTR f4 material_compute(const DScene& S, Stack& st, const ShadeRec& m, const RayState& ray, d3 point, const Isect& in, Cnt& cnt,
+NR_MAT_ATTR f4 material_compute(const DScene& S, Stack& st, const ShadeRec& m, RayState& ray, d3& point, Isect& in, Cnt& cnt,
                                 bool pre, bool pre_lit, f3 pre_filter, uint32_t lsl = 0u) {
     if (((m.flags >> 8) & 0xffu) != NRAYS_MAT_PHONG) return material_ambiant<STATS>(m, in, cnt);
     f4 tex; tex.x = tex.y = tex.z = tex.w = 1.0f;
@@ -1125,7 +1150,17 @@ NR_MAT_ATTR f4 material_compute(const DScene& S, Stack& st, const ShadeRec& m, c
             } else {
                 cnt.shadow++;
                 NR_TIC(tsq);
+                // kFeatPark: what the Phong terms below need of this hit waits in LDS while the shadow ray is traced (the values are the same
+                // bits afterwards; `in.n`, `point` and `ray.d` are the caller's objects, so its later uses read the reloaded registers too)
+                if (FEAT & kFeatPark) {
+                    st.park_d3(0, normal); st.park_d3(6, point); st.park_d3(12, ray.d);
+                    if (park_slots(FEAT) >= 25) { st.park_f(18, tex.x); st.park_f(19, tex.y); st.park_f(20, tex.z); st.park_f(21, tex.w); st.park_f(22, res.x); st.park_f(23, res.y); st.park_f(24, res.z); }
+                }
                 const bool blocked = shadow_query<STATS, FEAT>(S, st, so, ldir, dist, filter, cnt);
+                if (FEAT & kFeatPark) {
+                    normal = st.unpark_d3(0); in.n = normal; point = st.unpark_d3(6); ray.d = st.unpark_d3(12);
+                    if (park_slots(FEAT) >= 25) { tex.x = st.unpark_f(18); tex.y = st.unpark_f(19); tex.z = st.unpark_f(20); tex.w = st.unpark_f(21); res.x = st.unpark_f(22); res.y = st.unpark_f(23); res.z = st.unpark_f(24); }
+                }
                 NR_TOC(cyc_shadow, tsq);
                 if (blocked) continue; // shadowed
             }
@@ -1268,7 +1303,16 @@ NR_DEV f3 shade_hit(const DScene& S, Stack& st, RayState& ray, uint32_t depth, u
             pre = true;
             NR_TOC(cyc_x[3], tsh);
             NR_TIC(tsq);
+            // kFeatPark: the hit's record and the ray wait in LDS while the shadow ray is traced (the same bits come back)
+            if (FEAT & kFeatPark) {
+                st.park_d3(0, is.n); st.park_d3(6, ray.d); st.park_d(12, hit.t);
+                if (park_slots(FEAT) >= 24) { st.park_d3(14, ray.o); st.park_d(20, is.u); st.park_d(22, is.v); }
+            }
             pre_lit = !shadow_query<STATS, FEAT>(S, st, point + ldir * 0.001, ldir, nrm - 0.001, pre_filter, cnt);
+            if (FEAT & kFeatPark) {
+                is.n = st.unpark_d3(0); ray.d = st.unpark_d3(6); hit.t = st.unpark_d(12);
+                if (park_slots(FEAT) >= 24) { ray.o = st.unpark_d3(14); is.u = st.unpark_d(20); is.v = st.unpark_d(22); }
+            }
             NR_TOC(cyc_shadow, tsq);
 #ifdef NR_PHASE_TIMING
             tsh = __builtin_readcyclecounter();

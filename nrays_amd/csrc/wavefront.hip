@@ -196,6 +196,7 @@ struct WfStackInit {
         st.spill_stride = gridDim.x * kBlock;
         st.spill = spill ? (global_u32*)(spill + (size_t)blockIdx.x * kBlock + threadIdx.x) : nullptr;
         st.lds0 = Stack::addr((lds_u32*)lds_stack);
+        st.park = nullptr;
         st.init();
     }
 };
@@ -487,7 +488,7 @@ __global__ void __launch_bounds__(kBlock, NR_WF_OCC_SHADE) k_wf_shade(DScene S, 
                 }
                 is.toi = hit.t;
                 const ShadeRec& sn = S.shade[node_id];
-                const d3 pt = ray.o + ray.d * hit.t;
+                d3 pt = ray.o + ray.d * hit.t;
                 f4 obj;
                 if constexpr (MULTI) obj = wf_material_lit(S, sn, ray, pt, is, cnt, shres, (size_t)q.slots, at);
                 else obj = material_compute<false, FEAT>(S, st, sn, ray, pt, is, cnt, pre, pre_lit, pre_filter, 0u);
