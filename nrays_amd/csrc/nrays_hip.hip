@@ -139,8 +139,11 @@ constexpr int waves_per_simd(int feat) { return (feat & ~(kFeatMultiSample | kFe
 // OCC != 0: the alpha-shadow mesh permutations also exist at three waves per SIMD (168 VGPRs, ~64 dwords of scratch per lane): a
 // wave then runs slower, which lengthens a frame that is as long as its longest tile (sponza 1080p: 1.40 -> 1.67 ms) and shortens a
 // frame that is bound by the sum of its tiles (sponza 4K: 4.12 -> 3.65 ms, config 4: 14.6 -> 12.5 ms) — render_impl chooses per frame.
+#ifndef NR_OCC3_AS
+#define NR_OCC3_AS 3 // waves per SIMD the OCC = 3 permutations are compiled and launched for (experiments: 4)
+#endif
 template <bool STATS, int FEAT, bool PLAIN = false, int OCC = 0>
-__global__ void __launch_bounds__(kBlock, OCC ? OCC : waves_per_simd(FEAT)) k_primary(DScene S0, DRender R, QueueOut qo, float* __restrict__ out, DeviceCounters* ctr,
+__global__ void __launch_bounds__(kBlock, OCC ? NR_OCC3_AS : waves_per_simd(FEAT)) k_primary(DScene S0, DRender R, QueueOut qo, float* __restrict__ out, DeviceCounters* ctr,
                                                      uint32_t* spill, uint32_t tiles_x, uint32_t tiles_y, uint32_t* work_counters, uint32_t grab_arg,
                                                      uint32_t* zero_counts, DeviceCounters* zero_ctr) {
     // The scheduling path is fixed by the permutation — workgroup lists (0) for analytic-only scenes, XCD-aware HBM
@@ -977,7 +980,7 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
         if (sc->occ_override >= 0) occ = sc->occ_override == 3 ? 3 : 0;
     }
     uint32_t grid_primary = std::min<uint32_t>(std::min<uint32_t>(((ntiles + 7u) / 8u) * 8u, (uint32_t)kMaxGrid),
-                                                     (uint32_t)sc->num_cus * (uint32_t)(occ ? occ : waves_per_simd(instrumented ? kFeatAll : sc->features)) * 256u / (uint32_t)kBlock);
+                                                     (uint32_t)sc->num_cus * (uint32_t)(occ ? NR_OCC3_AS : waves_per_simd(instrumented ? kFeatAll : sc->features)) * 256u / (uint32_t)kBlock);
     if (sc->grid_wg_per_cu > 0) grid_primary = std::min<uint32_t>(grid_primary, (uint32_t)sc->num_cus * (uint32_t)sc->grid_wg_per_cu); // NRAYS_GRID_WG_PER_CU: occupancy sensitivity runs
 
     // All per-handle state (double-buffered counters, queues, raygen tables, tile costs) assumes that the renders of one

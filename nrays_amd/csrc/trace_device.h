@@ -37,7 +37,13 @@ constexpr int32_t kSentinel = (int32_t)0x80000001; // marks "leave the BLAS" on 
 // (160 KiB per CU; three workgroups of 24 KiB of stack + 25 KiB: with 29 dwords a third workgroup no longer fitted and config 4 went from
 // 10.8 to 14.9 ms): the three-wave alpha-shadow kernels 25 (several lights) / 24 (one light).  The four-wave opaque-mesh kernel gains
 // nothing from 14 parked dwords (hairball 2.02 ms either way, 16 spp 19.0 -> 19.2): it has no kFeatPark permutation.
-constexpr int park_slots(int feat) { return !(feat & kFeatPark) ? 0 : ((feat & kFeatMultiSample) ? 25 : 24); }
+#ifndef NR_PARK_CAP
+#define NR_PARK_CAP 25
+#endif
+constexpr int park_slots(int feat) {
+    return !(feat & kFeatPark) || !(feat & kFeatAlphaShadow) ? 0
+         : ((feat & kFeatMultiSample) ? (NR_PARK_CAP < 25 ? NR_PARK_CAP : 25) : (NR_PARK_CAP < 24 ? NR_PARK_CAP : 24));
+}
 constexpr int32_t kParked = (int32_t)0x80000002;   // a lane that yielded its node phase (traverse(): node_quorum); like kEmptyChild / kSentinel not a leaf ref
                                                    // that can occur (first = 2^28 - 1: scene_build.cpp refuses scenes that large)
 
@@ -1152,13 +1158,13 @@ NR_MAT_ATTR f4 material_compute(const DScene& S, Stack& st, const ShadeRec& m, R
                 NR_TIC(tsq);
                 // kFeatPark: what the Phong terms below need of this hit waits in LDS while the shadow ray is traced (the values are the same
                 // bits afterwards; `in.n`, `point` and `ray.d` are the caller's objects, so its later uses read the reloaded registers too)
-                if (FEAT & kFeatPark) {
-                    st.park_d3(0, normal); st.park_d3(6, point); st.park_d3(12, ray.d);
+                if ((FEAT & kFeatPark) && (FEAT & kFeatAlphaShadow) && park_slots(FEAT) >= 12) {
+                    st.park_d3(0, normal); st.park_d3(6, point); if (park_slots(FEAT) >= 18) st.park_d3(12, ray.d);
                     if (park_slots(FEAT) >= 25) { st.park_f(18, tex.x); st.park_f(19, tex.y); st.park_f(20, tex.z); st.park_f(21, tex.w); st.park_f(22, res.x); st.park_f(23, res.y); st.park_f(24, res.z); }
                 }
                 const bool blocked = shadow_query<STATS, FEAT>(S, st, so, ldir, dist, filter, cnt);
-                if (FEAT & kFeatPark) {
-                    normal = st.unpark_d3(0); in.n = normal; point = st.unpark_d3(6); ray.d = st.unpark_d3(12);
+                if ((FEAT & kFeatPark) && (FEAT & kFeatAlphaShadow) && park_slots(FEAT) >= 12) {
+                    normal = st.unpark_d3(0); in.n = normal; point = st.unpark_d3(6); if (park_slots(FEAT) >= 18) ray.d = st.unpark_d3(12);
                     if (park_slots(FEAT) >= 25) { tex.x = st.unpark_f(18); tex.y = st.unpark_f(19); tex.z = st.unpark_f(20); tex.w = st.unpark_f(21); res.x = st.unpark_f(22); res.y = st.unpark_f(23); res.z = st.unpark_f(24); }
                 }
                 NR_TOC(cyc_shadow, tsq);
@@ -1304,12 +1310,12 @@ NR_DEV f3 shade_hit(const DScene& S, Stack& st, RayState& ray, uint32_t depth, u
             NR_TOC(cyc_x[3], tsh);
             NR_TIC(tsq);
             // kFeatPark: the hit's record and the ray wait in LDS while the shadow ray is traced (the same bits come back)
-            if (FEAT & kFeatPark) {
+            if ((FEAT & kFeatPark) && (FEAT & kFeatAlphaShadow)) {
                 st.park_d3(0, is.n); st.park_d3(6, ray.d); st.park_d(12, hit.t);
                 if (park_slots(FEAT) >= 24) { st.park_d3(14, ray.o); st.park_d(20, is.u); st.park_d(22, is.v); }
             }
             pre_lit = !shadow_query<STATS, FEAT>(S, st, point + ldir * 0.001, ldir, nrm - 0.001, pre_filter, cnt);
-            if (FEAT & kFeatPark) {
+            if ((FEAT & kFeatPark) && (FEAT & kFeatAlphaShadow)) {
                 is.n = st.unpark_d3(0); ray.d = st.unpark_d3(6); hit.t = st.unpark_d(12);
                 if (park_slots(FEAT) >= 24) { ray.o = st.unpark_d3(14); is.u = st.unpark_d(20); is.v = st.unpark_d(22); }
             }
