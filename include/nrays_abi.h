@@ -278,6 +278,27 @@ int nrays_debug_node_aabb(NraysScene* scene, uint32_t node, double out[6]);
  * BVT queries end their node phases by quorum (NRAYS_NODE_QUORUM=0 in the environment of nrays_scene_create turns that off). */
 int nrays_debug_scene_flags(const NraysScene* scene, uint32_t out[2]);
 
+/* Test probe of `Scene::new`'s BVT construction for one TriMesh (src/scene.rs:119-133; ncollide's BVT::new_balanced inside TriMesh::new,
+ * examples/loader3d.rs:695): builds the BLAS of `mesh` with the host builder (flags bit 0 clear) or the device builder (bit 0 set;
+ * nrays_scene_create picks it for meshes from NRAYS_GPU_BUILD_MIN triangles, default 50 000), bit 1 = without triangle pre-splitting,
+ * and copies it out: `nodes` = num_nodes x 32 floats (the 128-byte 4-wide node: planes by slot, child refs in slot 2, local
+ * indices, depth-first order), `tri_ids` = the triangle index behind each of the num_refs leaf slots.  Both builders apply the same
+ * split rule with the same arithmetic, so from the same references they return the same nodes.  The caller provides the buffers
+ * (node_capacity / ref_capacity entries); all HOST memory.  Blocking. */
+typedef struct NraysBlasDump {
+    uint32_t num_nodes;
+    uint32_t num_refs;
+    int32_t root;      /* >= 0: node index, < 0: a single leaf */
+    int32_t max_depth;
+    uint32_t hairy;    /* the mesh was classified hair-like (aggressive pre-splitting, quorum-ended node phases) */
+    uint32_t node_capacity;
+    uint32_t ref_capacity;
+    uint32_t pad;
+    float* nodes;
+    uint32_t* tri_ids;
+} NraysBlasDump;
+int nrays_debug_blas_build(const NraysMesh* mesh, uint32_t flags, NraysBlasDump* out);
+
 /* Device bytes of the flattened scene (BVH nodes, triangle records, instance / shading records, textures): what
  * a frame must read at least once — the compulsory part of bench.py's roofline block. */
 uint64_t nrays_scene_device_bytes(const NraysScene* scene);

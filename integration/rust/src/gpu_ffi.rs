@@ -176,6 +176,21 @@ pub struct NraysCastResult {
     pub flags: u32,
 }
 
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct NraysBlasDump {
+    pub num_nodes: u32,
+    pub num_refs: u32,
+    pub root: i32,
+    pub max_depth: i32,
+    pub hairy: u32,
+    pub node_capacity: u32,
+    pub ref_capacity: u32,
+    pub pad: u32,
+    pub nodes: *mut f32,
+    pub tri_ids: *mut u32,
+}
+
 pub enum NraysScene {}
 pub enum NraysComm {}
 pub enum NraysSceneSet {}
@@ -195,6 +210,7 @@ extern "C" {
     pub fn nrays_untile_device(gathered: *const f32, out_rgb_device: *mut f32, width: u32, height: u32, band_rows: u32, band_owners: u32, hip_stream: *mut c_void) -> c_int;
     pub fn nrays_get_stats(scene: *mut NraysScene, out_stats: *mut NraysStats) -> c_int;
     pub fn nrays_get_primary_kernel_stats(scene: *mut NraysScene, out_stats: *mut NraysStats) -> c_int;
+    pub fn nrays_debug_blas_build(mesh: *const NraysMesh, flags: u32, out: *mut NraysBlasDump) -> c_int;
     pub fn nrays_debug_node_aabb(scene: *mut NraysScene, node: u32, out: *mut f64) -> c_int;
     pub fn nrays_debug_scene_flags(scene: *const NraysScene, out: *mut u32) -> c_int;
     pub fn nrays_get_tile_costs(scene: *mut NraysScene, out: *mut NraysTileCosts) -> c_int;

@@ -107,8 +107,14 @@ class NraysCastResult(C.Structure):
     _fields_ = [("toi", C.c_double), ("normal", C.c_double * 3), ("uv", C.c_double * 2), ("node_id", C.c_int32), ("flags", C.c_uint32)]
 
 
+class NraysBlasDump(C.Structure):
+    _fields_ = [("num_nodes", C.c_uint32), ("num_refs", C.c_uint32), ("root", C.c_int32), ("max_depth", C.c_int32), ("hairy", C.c_uint32),
+                ("node_capacity", C.c_uint32), ("ref_capacity", C.c_uint32), ("pad", C.c_uint32), ("nodes", C.POINTER(C.c_float)), ("tri_ids", C.POINTER(C.c_uint32))]
+
+
 # Every symbol include/nrays_abi.h declares, with its ctypes signature.
 HIP_SYMBOLS = {
+    "nrays_debug_blas_build": (C.c_int, [C.POINTER(NraysMesh), C.c_uint32, C.POINTER(NraysBlasDump)]),
     "nrays_debug_node_aabb": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_double)]),
     "nrays_debug_scene_flags": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "nrays_get_tile_costs": (C.c_int, [C.c_void_p, C.POINTER(NraysTileCosts)]),

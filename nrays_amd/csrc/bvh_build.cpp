@@ -42,13 +42,7 @@ struct Box {
     }
 };
 
-#ifndef NR_SAH_BINS
-#define NR_SAH_BINS 32 // 16 -> 32: hairball -1 %, sponza -0.4 %, same build time
-#endif
-constexpr int kBins = NR_SAH_BINS;
-#ifndef NR_PRIM_COST
-#define NR_PRIM_COST 0.5f // re-tuned with the prefetching leaf loop (0.7 before): sponza -0.8 %, hairball -4 %
-#endif
+constexpr int kBins = kSahBins;
 constexpr float kPrimCost = NR_PRIM_COST;
 
 struct Node2 { // binary node produced by the SAH build, collapsed into 4-wide BvhNodes afterwards

@@ -1,0 +1,965 @@
+// bvh_device.hip — the BLAS of a large TriMesh group built on the GPU (see bvh_device.h).
+//
+// Stages (all on the current device, null stream):
+//   1. k_tri_records      triangle records / uvs / f32 boxes from the caller's f64 vertex arrays (+ the f32-exactness checks)
+//   2. k_presplit         pre-splitting of thin diagonal triangles (presplit_clip.h: the host builder's clip arithmetic); the
+//                         threshold a budget amounts to comes from a histogram of the empty areas of ALL pieces instead of the
+//                         host's heap over a sample
+//   3. binned-SAH binary build, the split rule of bvh_build.cpp bit for bit (32 bins on the centroid bounds, three axes, the first
+//      minimum in (axis, bin) order, the SAH leaf criterion):
+//        large nodes (> kSmall references) level by level — k_bin (LDS bins per 1024-reference chunk, merged with encoded
+//        atomics), k_select (one wave per node), k_part_scan + k_scatter (stable partition between two order buffers);
+//        small nodes — k_small: ONE WAVE builds the whole subtree of a node in LDS.
+//      A binary node is stored at index (split position - 1): no allocation, no atomics, deterministic.
+//   4. collapse into the 128-byte 4-wide nodes of device_types.h (the host Collapser's rule) level by level, subtree sizes bottom-up,
+//      then the host builder's depth-first node order top-down, refs rebased to the scene's arrays
+//   5. k_gather           leaf-ordered triangle records and uvs
+// min / max / counts are exact and the costs are evaluated with the host's f32 operations (-ffp-contract=off), so from the same
+// references both builders produce the same tree (tests/test_device_build_gpu.py compares the node arrays).
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <map>
+
+#include "../../include/nrays_abi.h"
+#include "bvh_build.h"
+#include "bvh_device.h"
+#include "presplit_clip.h"
+
+namespace nrays {
+namespace {
+
+static_assert(kSahBins == 32, "the device builder maps one SAH bin to one lane of a 32-lane half wave");
+constexpr uint32_t kChunk = 1024;  // references per workgroup of the large-node kernels
+constexpr uint32_t kSmall = 256;   // nodes up to this many references are finished by one wave in LDS
+constexpr int kBinWords = 96 * 6;  // min (or max) words of one node's bins: [axis][bin][box xyz, centroid xyz]
+constexpr uint32_t kHistShift = 13, kHistBins = 1u << (32 - kHistShift);
+#define INF_F __builtin_huge_valf()
+
+struct Task {
+    uint32_t first, count;
+    int32_t parent;  // binary node whose child this range is (-1: the root)
+    uint32_t flags;  // kTaskSide: right child; kTaskBuf: which order buffer holds the range
+    float bmn[3], bmx[3], cmn[3], cmx[3]; // bounds of the boxes / of the centroids
+};
+static_assert(sizeof(Task) == 64, "Task layout");
+enum : uint32_t { kTaskSide = 1u, kTaskBuf = 2u };
+
+struct Node2 { float lmin[3], lmax[3], rmin[3], rmax[3]; int32_t left, right; };
+
+struct SplitInfo { int32_t axis; int32_t split; uint32_t mid; float lo, scale; }; // axis < 0: the range is not scattered
+
+struct Counters {
+    uint32_t n_next, n_small, overflow, n_binary;
+    int32_t root_ref;
+    uint32_t err;        // bit 0: index out of range, bit 1: vertex not f32-exact, bit 2: uv not f32-exact
+    uint32_t next_id;    // collapse: compact ids handed out
+    uint32_t pad;
+    unsigned long long phase[8]; // tuning builds (NR_BUILD_PHASES): wave cycles of k_small's phases
+    uint32_t bounds[12]; // encoded: box min xyz, centroid min xyz, box max xyz, centroid max xyz (root pass, BLAS bounds)
+};
+
+// ---- order-preserving float <-> uint encoding (min / max through integer atomics) -----------------------------------
+__device__ inline uint32_t enc(float f) { uint32_t b = __float_as_uint(f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
+__device__ inline float dec(uint32_t e) { return __uint_as_float((e & 0x80000000u) ? (e & 0x7fffffffu) : ~e); }
+__device__ inline float dec_min(uint32_t e) { return e == 0xffffffffu ? INF_F : dec(e); } // identity of min = all ones (memset 0xff)
+__device__ inline float dec_max(uint32_t e) { return e == 0u ? -INF_F : dec(e); }          // identity of max = zero (memset 0)
+
+__device__ inline float half_area3(const float mn[3], const float mx[3]) { // bvh_build.cpp: Box::half_area
+    float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
+    if (!(dx >= 0.f) || !(dy >= 0.f) || !(dz >= 0.f)) return 0.f;
+    return dx * dy + dy * dz + dz * dx;
+}
+#ifdef NR_BUILD_PHASES
+#define PHASE_BEGIN() unsigned long long ph_t0 = __builtin_readcyclecounter(); unsigned long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define PHASE(k) do { unsigned long long ph_t1 = __builtin_readcyclecounter(); ph_acc[k] += ph_t1 - ph_t0; ph_t0 = ph_t1; } while (0)
+#define PHASE_END(ctr) do { if (lane_id() == 0) for (int k_ = 0; k_ < 8; ++k_) if (ph_acc[k_]) atomicAdd(&(ctr)->phase[k_], ph_acc[k_]); } while (0)
+#else
+#define PHASE_BEGIN() do {} while (0)
+#define PHASE(k) do {} while (0)
+#define PHASE_END(ctr) do {} while (0)
+#endif
+__device__ inline void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+__device__ inline int lane_id() { return (int)(threadIdx.x & 63u); }
+__device__ inline float bcast_f(float v, int src) { return __shfl(v, src, 64); }
+__device__ inline uint32_t bcast_u(uint32_t v, int src) { return (uint32_t)__shfl((int)v, src, 64); }
+
+__device__ inline void load_box(const float* ref_box, uint32_t id, float mn[3], float mx[3]) {
+    const float2* p = reinterpret_cast<const float2*>(ref_box + 6 * (size_t)id);
+    float2 a = p[0], b = p[1], c = p[2];
+    mn[0] = a.x; mn[1] = a.y; mn[2] = b.x; mx[0] = b.y; mx[1] = c.x; mx[2] = c.y;
+}
+__device__ inline int bin_of(float cent, float lo, float scale) {
+    int b = (int)((cent - lo) * scale);
+    return min(max(b, 0), kSahBins - 1);
+}
+
+// ---- the split rule of Builder::build for one node, evaluated by one wave ---------------------------------------------
+// bins: mn / mx = kBinWords encoded words each, cnt = 96 counts ([axis][bin]); every argument and every result is wave-uniform.
+struct SplitResult {
+    int axis, split; // axis < 0: every centroid coincides (split by index)
+    bool leaf;
+    uint32_t nleft;
+    float lb_mn[3], lb_mx[3], lc_mn[3], lc_mx[3], rb_mn[3], rb_mx[3], rc_mn[3], rc_mx[3];
+};
+__device__ void select_split(const uint32_t* mn, const uint32_t* mx, const uint32_t* cnt, const Task& t, int max_leaf, float prim_cost, SplitResult& r) {
+    const int lane = lane_id(), half = lane >> 5, j = lane & 31;
+    const int bin = half ? 31 - j : j; // lower half: prefix over bins 0..j; upper half: suffix over bins 31-j..31
+    float best_cost = INF_F; int best_key = -1;
+    for (int axis = 0; axis < 3; ++axis) {
+        if (!(t.cmx[axis] > t.cmn[axis])) continue;
+        const int idx = axis * 32 + bin;
+        float bmn[3], bmx[3];
+        for (int a = 0; a < 3; ++a) { bmn[a] = dec_min(mn[idx * 6 + a]); bmx[a] = dec_max(mx[idx * 6 + a]); }
+        uint32_t c = cnt[idx];
+        for (int off = 1; off < 32; off <<= 1) {
+            float on[3], ox[3];
+            for (int a = 0; a < 3; ++a) { on[a] = __shfl_up(bmn[a], off, 32); ox[a] = __shfl_up(bmx[a], off, 32); }
+            uint32_t oc = (uint32_t)__shfl_up((int)c, off, 32);
+            if (j >= off) { for (int a = 0; a < 3; ++a) { bmn[a] = fminf(bmn[a], on[a]); bmx[a] = fmaxf(bmx[a], ox[a]); } c += oc; }
+        }
+        const float area = half_area3(bmn, bmx);
+        const int src = lane <= 30 ? 62 - lane : lane; // the suffix over bins lane+1..31 sits in lane 32 + (31 - (lane + 1))
+        const float rarea = __shfl(area, src, 64);
+        const uint32_t rc = (uint32_t)__shfl((int)c, src, 64);
+        if (lane <= 30 && c > 0u && rc > 0u) {
+            const float cost = area * (float)c + rarea * (float)rc;
+            if (cost < best_cost) { best_cost = cost; best_key = axis * 32 + lane; }
+        }
+    }
+    for (int off = 32; off >= 1; off >>= 1) { // first minimum in (axis, bin) order, like the sequential sweep
+        const float oc = __shfl_xor(best_cost, off, 64);
+        const int ok = __shfl_xor(best_key, off, 64);
+        if (ok >= 0 && (best_key < 0 || oc < best_cost || (oc == best_cost && ok < best_key))) { best_cost = oc; best_key = ok; }
+    }
+    r.leaf = false;
+    if ((int)t.count <= max_leaf) { // SAH: an exact f64 ray / triangle test costs about prim_cost times a node visit
+        const float ha = half_area3(t.bmn, t.bmx);
+        const float leaf_cost = ha * (float)t.count * prim_cost;
+        const float split_cost = best_key < 0 ? INF_F : best_cost * prim_cost + ha * 1.0f;
+        if (!(split_cost < leaf_cost)) r.leaf = true;
+    }
+    r.axis = best_key < 0 ? -1 : best_key >> 5;
+    r.split = best_key < 0 ? 0 : best_key & 31;
+    r.nleft = 0;
+    if (r.leaf || best_key < 0) return;
+    // children: lower half reduces the bins <= split, upper half the bins above
+    const int idx = r.axis * 32 + j;
+    const bool mine = half == 0 ? j <= r.split : j > r.split;
+    float v[12]; // box min, centroid min, box max, centroid max
+    for (int a = 0; a < 6; ++a) { v[a] = mine ? dec_min(mn[idx * 6 + a]) : INF_F; v[6 + a] = mine ? dec_max(mx[idx * 6 + a]) : -INF_F; }
+    uint32_t c = mine ? cnt[idx] : 0u;
+    for (int off = 16; off >= 1; off >>= 1) {
+        for (int a = 0; a < 6; ++a) { v[a] = fminf(v[a], __shfl_xor(v[a], off, 64)); v[6 + a] = fmaxf(v[6 + a], __shfl_xor(v[6 + a], off, 64)); }
+        c += (uint32_t)__shfl_xor((int)c, off, 64);
+    }
+    for (int a = 0; a < 3; ++a) {
+        r.lb_mn[a] = bcast_f(v[a], 0); r.lc_mn[a] = bcast_f(v[3 + a], 0); r.lb_mx[a] = bcast_f(v[6 + a], 0); r.lc_mx[a] = bcast_f(v[9 + a], 0);
+        r.rb_mn[a] = bcast_f(v[a], 32); r.rc_mn[a] = bcast_f(v[3 + a], 32); r.rb_mx[a] = bcast_f(v[6 + a], 32); r.rc_mx[a] = bcast_f(v[9 + a], 32);
+    }
+    r.nleft = bcast_u(c, 0);
+}
+
+// Twelve-value wave reduction (min of v[0..5], max of v[6..11]); the result is uniform.
+__device__ inline void wave_reduce12(float v[12]) {
+    for (int off = 32; off >= 1; off >>= 1)
+        for (int a = 0; a < 6; ++a) { v[a] = fminf(v[a], __shfl_xor(v[a], off, 64)); v[6 + a] = fmaxf(v[6 + a], __shfl_xor(v[6 + a], off, 64)); }
+}
+__device__ inline void acc12(float v[12], const float mn[3], const float mx[3]) {
+    for (int a = 0; a < 3; ++a) {
+        const float ce = 0.5f * mn[a] + 0.5f * mx[a];
+        v[a] = fminf(v[a], mn[a]); v[3 + a] = fminf(v[3 + a], ce); v[6 + a] = fmaxf(v[6 + a], mx[a]); v[9 + a] = fmaxf(v[9 + a], ce);
+    }
+}
+__device__ inline void init12(float v[12]) { for (int a = 0; a < 6; ++a) { v[a] = INF_F; v[6 + a] = -INF_F; } }
+
+__device__ inline void set_ref(Node2* node2, Counters* ctr, int32_t parent, uint32_t flags, int32_t ref) {
+    if (parent < 0) ctr->root_ref = ref;
+    else if (flags & kTaskSide) node2[parent].right = ref; else node2[parent].left = ref;
+}
+__device__ inline void make_task(Task& c, uint32_t first, uint32_t count, int32_t parent, uint32_t flags, const float bmn[3], const float bmx[3], const float cmn[3], const float cmx[3]) {
+    c.first = first; c.count = count; c.parent = parent; c.flags = flags;
+    for (int a = 0; a < 3; ++a) { c.bmn[a] = bmn[a]; c.bmx[a] = bmx[a]; c.cmn[a] = cmn[a]; c.cmx[a] = cmx[a]; }
+}
+
+// ---- stage 1: triangle records ----------------------------------------------------------------------------------------
+struct PartDev { const double* vertices; const double* uvs; const uint32_t* indices; uint32_t num_vertices, num_triangles, node_id, tri_base; };
+
+__global__ __launch_bounds__(256) void k_tri_records(PartDev part, TriRec* recs, TriUv* uvs, float* tbox, double* part_area, double* part_tri2,
+                                                     uint32_t block_base, Counters* ctr) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    double ha = 0.0, ta = 0.0;
+    float v12[12]; init12(v12);
+    uint32_t err = 0;
+    if (t < part.num_triangles) {
+        TriRec r; TriUv uv; PrimBounds b;
+        for (int k = 0; k < 6; ++k) uv.uv[k] = 0.0f;
+        for (int a = 0; a < 3; ++a) { b.mn[a] = INF_F; b.mx[a] = -INF_F; }
+        float* vs[3] = {r.v0, r.v1, r.v2};
+        for (int k = 0; k < 3; ++k) {
+            uint32_t vi = part.indices[3 * (size_t)t + k];
+            if (vi >= part.num_vertices) { err |= 1u; vi = 0; }
+            for (int a = 0; a < 3; ++a) {
+                const double x = part.vertices[3 * (size_t)vi + a];
+                const float f = (float)x;
+                if (!((double)f == x)) err |= 2u; // also rejects NaN
+                vs[k][a] = f;
+                b.mn[a] = fminf(b.mn[a], f); b.mx[a] = fmaxf(b.mx[a], f);
+            }
+            if (part.uvs) for (int a = 0; a < 2; ++a) {
+                const double x = part.uvs[2 * (size_t)vi + a];
+                const float f = (float)x;
+                if (!((double)f == x)) err |= 4u;
+                uv.uv[2 * k + a] = f;
+            }
+        }
+        r.node_id = part.node_id; r.tri_id = t; r.pad = 0;
+        const size_t g = (size_t)part.tri_base + t;
+        recs[g] = r; uvs[g] = uv;
+        for (int a = 0; a < 3; ++a) { tbox[6 * g + a] = b.mn[a]; tbox[6 * g + 3 + a] = b.mx[a]; }
+        ClipPoly p; tri_poly(r, p);
+        ha = box_half_area(b); ta = poly_area2(p);
+        for (int a = 0; a < 3; ++a) { v12[a] = b.mn[a]; v12[6 + a] = b.mx[a]; }
+    }
+    // deterministic block sums (fixed tree), mesh bounds through encoded atomics
+    __shared__ double s_a[256], s_t[256];
+    s_a[threadIdx.x] = ha; s_t[threadIdx.x] = ta;
+    __syncthreads();
+    for (uint32_t s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) { s_a[threadIdx.x] += s_a[threadIdx.x + s]; s_t[threadIdx.x] += s_t[threadIdx.x + s]; } __syncthreads(); }
+    if (threadIdx.x == 0) { part_area[block_base + blockIdx.x] = s_a[0]; part_tri2[block_base + blockIdx.x] = s_t[0]; }
+    wave_reduce12(v12);
+    if (lane_id() == 0 && v12[0] <= v12[6]) for (int a = 0; a < 3; ++a) { atomicMin(&ctr->bounds[a], enc(v12[a])); atomicMax(&ctr->bounds[6 + a], enc(v12[6 + a])); }
+    const unsigned long long any = __ballot(err != 0);
+    if (any && err) atomicOr(&ctr->err, err);
+}
+
+// ---- stage 2: pre-splitting ---------------------------------------------------------------------------------------------
+struct SplitFrame { ClipPoly poly; PrimBounds box; int slot; int depth; };
+enum { kModeCount = 0, kModeHist = 1, kModeEmit = 2 };
+// One thread walks the split tree of one triangle exactly like split_rec() of scene_build.cpp (low half first; the high half's
+// reference slot is reserved when the split happens).  kModeHist also files the empty area of every split; kModeEmit writes boxes.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_presplit(const TriRec* recs, const float* tbox, uint32_t n, double thr, SplitFrame* frames, uint32_t* counts,
+                                                  const uint32_t* offsets, uint32_t* hist, float* ref_box, uint32_t* ref_tri) {
+    SplitFrame* stack = frames + (size_t)(blockIdx.x * 256u + threadIdx.x) * (kSplitDepthMax + 1);
+    for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < n; t += gridDim.x * 256u) {
+        ClipPoly cur; PrimBounds box; int slot = -1, depth = 0, sp = 0, next = 0;
+        tri_poly(recs[t], cur);
+        for (int a = 0; a < 3; ++a) { box.mn[a] = tbox[6 * (size_t)t + a]; box.mx[a] = tbox[6 * (size_t)t + 3 + a]; }
+        for (;;) {
+            const double ha = box_half_area(box);
+            const double gain = ha - poly_area2(cur);
+            ClipPoly lo, hi; PrimBounds bl, bh;
+            if (depth >= kSplitDepthMax || !piece_qualifies(ha, gain, thr) || !split_piece(cur, box, lo, hi, bl, bh)) {
+                if (MODE == kModeEmit) {
+                    const size_t r = slot < 0 ? (size_t)t : (size_t)n + offsets[t] + (uint32_t)slot;
+                    for (int a = 0; a < 3; ++a) { ref_box[6 * r + a] = box.mn[a]; ref_box[6 * r + 3 + a] = box.mx[a]; }
+                    ref_tri[r] = t;
+                }
+                if (sp == 0) break;
+                --sp;
+                cur = stack[sp].poly; box = stack[sp].box; slot = stack[sp].slot; depth = stack[sp].depth;
+                continue;
+            }
+            if (MODE == kModeHist) atomicAdd(&hist[__float_as_uint((float)gain) >> kHistShift], 1u);
+            stack[sp].poly = hi; stack[sp].box = bh; stack[sp].slot = next++; stack[sp].depth = depth + 1; ++sp;
+            cur = lo; box = bl; ++depth;
+        }
+        if (MODE != kModeEmit) counts[t] = (uint32_t)next;
+    }
+}
+__global__ void k_iota_refs(uint32_t n, const float* tbox, float* ref_box, uint32_t* ref_tri) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    for (int a = 0; a < 6; ++a) ref_box[6 * (size_t)i + a] = tbox[6 * (size_t)i + a];
+    ref_tri[i] = i;
+}
+
+// ---- stage 3: binary build ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_root_bounds(const float* ref_box, uint32_t nrefs, uint32_t* order0, Counters* ctr) {
+    float v[12]; init12(v);
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < nrefs; i += gridDim.x * 256u) {
+        float mn[3], mx[3]; load_box(ref_box, i, mn, mx);
+        acc12(v, mn, mx);
+        order0[i] = i;
+    }
+    wave_reduce12(v);
+    if (lane_id() == 0 && v[0] <= v[6]) for (int a = 0; a < 6; ++a) { atomicMin(&ctr->bounds[a], enc(v[a])); atomicMax(&ctr->bounds[6 + a], enc(v[6 + a])); }
+}
+__global__ void k_root_task(Task* tasks, Task* small, uint32_t nrefs, Counters* ctr) {
+    Task t; t.first = 0; t.count = nrefs; t.parent = -1; t.flags = 0;
+    for (int a = 0; a < 3; ++a) { t.bmn[a] = dec_min(ctr->bounds[a]); t.cmn[a] = dec_min(ctr->bounds[3 + a]); t.bmx[a] = dec_max(ctr->bounds[6 + a]); t.cmx[a] = dec_max(ctr->bounds[9 + a]); }
+    if (nrefs > kSmall) { tasks[0] = t; ctr->n_next = 1; ctr->n_small = 0; } else { small[0] = t; ctr->n_next = 0; ctr->n_small = 1; }
+}
+
+// chunk_base[t] = first chunk of task t (exclusive scan of ceil(count / kChunk)); one workgroup.
+__global__ __launch_bounds__(1024) void k_chunk_scan(const Task* tasks, uint32_t nt, uint32_t* chunk_base) {
+    __shared__ uint32_t s_sum[1024];
+    const uint32_t per = (nt + 1023u) / 1024u, lo = threadIdx.x * per, hi = min(nt, lo + per);
+    uint32_t sum = 0;
+    for (uint32_t i = lo; i < hi; ++i) sum += (tasks[i].count + kChunk - 1u) / kChunk;
+    s_sum[threadIdx.x] = sum;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024u; off <<= 1) { uint32_t v = threadIdx.x >= off ? s_sum[threadIdx.x - off] : 0u; __syncthreads(); s_sum[threadIdx.x] += v; __syncthreads(); }
+    uint32_t run = s_sum[threadIdx.x] - sum;
+    for (uint32_t i = lo; i < hi; ++i) { chunk_base[i] = run; run += (tasks[i].count + kChunk - 1u) / kChunk; }
+    if (threadIdx.x == 1023u) chunk_base[nt] = s_sum[1023];
+}
+
+__global__ __launch_bounds__(256) void k_bin(const Task* tasks, uint32_t nt, const uint32_t* chunk_base, uint32_t* chunk_task, const uint32_t* order0, const uint32_t* order1,
+                                             const float* ref_box, uint32_t* gmn, uint32_t* gmx, uint32_t* gcnt, uint32_t* chunk_cnt) {
+    __shared__ uint32_t smn[kBinWords], smx[kBinWords], scnt[96];
+    const uint32_t c = blockIdx.x;
+    uint32_t lo_t = 0, hi_t = nt; // last task whose chunk_base <= c
+    while (hi_t - lo_t > 1u) { const uint32_t m = (lo_t + hi_t) >> 1; if (chunk_base[m] <= c) lo_t = m; else hi_t = m; }
+    const uint32_t t = lo_t;
+    const Task tk = tasks[t];
+    if (threadIdx.x == 0) chunk_task[c] = t;
+    for (uint32_t i = threadIdx.x; i < (uint32_t)kBinWords; i += 256u) { smn[i] = 0xffffffffu; smx[i] = 0u; }
+    if (threadIdx.x < 96u) scnt[threadIdx.x] = 0u;
+    __syncthreads();
+    float scale[3]; bool use[3];
+    for (int a = 0; a < 3; ++a) { use[a] = tk.cmx[a] > tk.cmn[a]; scale[a] = use[a] ? (float)kSahBins / (tk.cmx[a] - tk.cmn[a]) : 0.0f; }
+    const uint32_t* order = (tk.flags & kTaskBuf) ? order1 : order0;
+    const uint32_t lo = tk.first + (c - chunk_base[t]) * kChunk, hi = min(tk.first + tk.count, lo + kChunk);
+    for (uint32_t pos = lo + threadIdx.x; pos < hi; pos += 256u) {
+        float mn[3], mx[3], ce[3]; load_box(ref_box, order[pos], mn, mx);
+        for (int a = 0; a < 3; ++a) ce[a] = 0.5f * mn[a] + 0.5f * mx[a];
+        for (int axis = 0; axis < 3; ++axis) {
+            if (!use[axis]) continue;
+            const int idx = axis * 32 + bin_of(ce[axis], tk.cmn[axis], scale[axis]);
+            for (int a = 0; a < 3; ++a) {
+                atomicMin(&smn[idx * 6 + a], enc(mn[a])); atomicMin(&smn[idx * 6 + 3 + a], enc(ce[a]));
+                atomicMax(&smx[idx * 6 + a], enc(mx[a])); atomicMax(&smx[idx * 6 + 3 + a], enc(ce[a]));
+            }
+            atomicAdd(&scnt[idx], 1u);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 96u) {
+        const uint32_t i = threadIdx.x, n = scnt[i];
+        chunk_cnt[(size_t)c * 96u + i] = n;
+        if (n) {
+            for (int a = 0; a < 6; ++a) { atomicMin(&gmn[(size_t)t * kBinWords + i * 6 + a], smn[i * 6 + a]); atomicMax(&gmx[(size_t)t * kBinWords + i * 6 + a], smx[i * 6 + a]); }
+            atomicAdd(&gcnt[(size_t)t * 96u + i], n);
+        }
+    }
+}
+
+// Bounds of order[lo, hi) by one wave (the split-by-index case: the halves are not unions of bins).
+__device__ void range_bounds_global(const uint32_t* order, const float* ref_box, uint32_t lo, uint32_t hi, float v[12]) {
+    init12(v);
+    for (uint32_t p = lo + (uint32_t)lane_id(); p < hi; p += 64u) { float mn[3], mx[3]; load_box(ref_box, order[p], mn, mx); acc12(v, mn, mx); }
+    wave_reduce12(v);
+}
+
+__global__ __launch_bounds__(256) void k_select(const Task* tasks, uint32_t nt, const uint32_t* gmn, const uint32_t* gmx, const uint32_t* gcnt, SplitInfo* split, Task* next, Task* small,
+                                                uint32_t small_cap, Node2* node2, const uint32_t* order0, const uint32_t* order1, uint32_t* order_final, const float* ref_box, Counters* ctr,
+                                                int max_leaf, float prim_cost) {
+    const uint32_t t = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (t >= nt) return;
+    const Task tk = tasks[t];
+    SplitResult r;
+    select_split(gmn + (size_t)t * kBinWords, gmx + (size_t)t * kBinWords, gcnt + (size_t)t * 96u, tk, max_leaf, prim_cost, r);
+    const uint32_t* order = (tk.flags & kTaskBuf) ? order1 : order0;
+    const int lane = lane_id();
+    SplitInfo si; si.axis = -1; si.split = 0; si.mid = 0; si.lo = 0.f; si.scale = 0.f;
+    if (r.leaf) { // (only when kSmall < max_leaf; kept for completeness)
+        for (uint32_t i = (uint32_t)lane; i < tk.count; i += 64u) order_final[tk.first + i] = order[tk.first + i];
+        if (lane == 0) { set_ref(node2, ctr, tk.parent, tk.flags, make_leaf_ref(tk.first, tk.count)); split[t] = si; }
+        return;
+    }
+    uint32_t mid, child_buf = tk.flags & kTaskBuf;
+    float L[12], R[12];
+    if (r.axis < 0) { // all centroids coincide: split by index, nothing moves
+        mid = tk.first + tk.count / 2u;
+        range_bounds_global(order, ref_box, tk.first, mid, L);
+        range_bounds_global(order, ref_box, mid, tk.first + tk.count, R);
+    } else {
+        mid = tk.first + r.nleft;
+        for (int a = 0; a < 3; ++a) {
+            L[a] = r.lb_mn[a]; L[3 + a] = r.lc_mn[a]; L[6 + a] = r.lb_mx[a]; L[9 + a] = r.lc_mx[a];
+            R[a] = r.rb_mn[a]; R[3 + a] = r.rc_mn[a]; R[6 + a] = r.rb_mx[a]; R[9 + a] = r.rc_mx[a];
+        }
+        si.axis = r.axis; si.split = r.split; si.mid = mid; si.lo = tk.cmn[r.axis]; si.scale = (float)kSahBins / (tk.cmx[r.axis] - tk.cmn[r.axis]);
+        child_buf ^= kTaskBuf;
+    }
+    if (lane != 0) return;
+    split[t] = si;
+    const int32_t me = (int32_t)(mid - 1u);
+    Node2 n;
+    for (int a = 0; a < 3; ++a) { n.lmin[a] = L[a]; n.lmax[a] = L[6 + a]; n.rmin[a] = R[a]; n.rmax[a] = R[6 + a]; }
+    n.left = kEmptyChild; n.right = kEmptyChild;
+    node2[me] = n;
+    set_ref(node2, ctr, tk.parent, tk.flags, me);
+    atomicAdd(&ctr->n_binary, 1u);
+    for (int side = 0; side < 2; ++side) {
+        const float* B = side ? R : L;
+        Task c; make_task(c, side ? mid : tk.first, side ? tk.first + tk.count - mid : mid - tk.first, me, child_buf | (side ? kTaskSide : 0u), B, B + 6, B + 3, B + 9);
+        if (c.count > kSmall) next[atomicAdd(&ctr->n_next, 1u)] = c;
+        else { const uint32_t k = atomicAdd(&ctr->n_small, 1u); if (k < small_cap) small[k] = c; else ctr->overflow = 1u; }
+    }
+}
+
+// chunk_off[c] = references of chunk c's task that go left and sit in earlier chunks of that task; one workgroup.
+__global__ __launch_bounds__(1024) void k_part_scan(const uint32_t* chunk_task, const uint32_t* chunk_base, const uint32_t* chunk_cnt, const SplitInfo* split, uint32_t nchunks,
+                                                    uint32_t* chunk_off, uint32_t* scratch) {
+    __shared__ uint32_t s_sum[1024];
+    const uint32_t per = (nchunks + 1023u) / 1024u, lo = threadIdx.x * per, hi = min(nchunks, lo + per);
+    auto lefts = [&](uint32_t c) -> uint32_t {
+        const SplitInfo si = split[chunk_task[c]];
+        if (si.axis < 0) return 0u;
+        uint32_t s = 0;
+        for (int b = 0; b <= si.split; ++b) s += chunk_cnt[(size_t)c * 96u + (uint32_t)(si.axis * 32 + b)];
+        return s;
+    };
+    uint32_t sum = 0;
+    for (uint32_t c = lo; c < hi; ++c) sum += lefts(c);
+    s_sum[threadIdx.x] = sum;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024u; off <<= 1) { uint32_t v = threadIdx.x >= off ? s_sum[threadIdx.x - off] : 0u; __syncthreads(); s_sum[threadIdx.x] += v; __syncthreads(); }
+    uint32_t run = s_sum[threadIdx.x] - sum;
+    for (uint32_t c = lo; c < hi; ++c) { scratch[c] = run; run += lefts(c); }
+    __threadfence_block();
+    __syncthreads();
+    for (uint32_t c = lo; c < hi; ++c) chunk_off[c] = scratch[c] - scratch[chunk_base[chunk_task[c]]];
+}
+
+__global__ __launch_bounds__(256) void k_scatter(const Task* tasks, const uint32_t* chunk_task, const uint32_t* chunk_base, const uint32_t* chunk_off, const SplitInfo* split,
+                                                 uint32_t* order0, uint32_t* order1, const float* ref_box) {
+    __shared__ uint32_t wl[4], wr[4];
+    const uint32_t c = blockIdx.x, t = chunk_task[c];
+    const SplitInfo si = split[t];
+    if (si.axis < 0) return;
+    const Task tk = tasks[t];
+    const uint32_t k = c - chunk_base[t];
+    const uint32_t lo = tk.first + k * kChunk, hi = min(tk.first + tk.count, lo + kChunk);
+    const uint32_t* src = (tk.flags & kTaskBuf) ? order1 : order0;
+    uint32_t* dst = (tk.flags & kTaskBuf) ? order0 : order1;
+    uint32_t lbase = tk.first + chunk_off[c], rbase = si.mid + (k * kChunk - chunk_off[c]);
+    const uint32_t w = threadIdx.x >> 6;
+    const unsigned long long lt = (1ull << lane_id()) - 1ull;
+    for (uint32_t base = lo; base < hi; base += 256u) {
+        const uint32_t pos = base + threadIdx.x;
+        const bool valid = pos < hi;
+        uint32_t id = 0; bool left = false;
+        if (valid) {
+            id = src[pos];
+            const float* b = ref_box + 6 * (size_t)id;
+            const float ce = 0.5f * b[si.axis] + 0.5f * b[3 + si.axis];
+            left = bin_of(ce, si.lo, si.scale) <= si.split;
+        }
+        const unsigned long long ml = __ballot(valid && left), mr = __ballot(valid && !left);
+        if (lane_id() == 0) { wl[w] = (uint32_t)__popcll(ml); wr[w] = (uint32_t)__popcll(mr); }
+        __syncthreads();
+        uint32_t lp = 0, rp = 0, lsum = 0, rsum = 0;
+        for (uint32_t q = 0; q < 4u; ++q) { if (q < w) { lp += wl[q]; rp += wr[q]; } lsum += wl[q]; rsum += wr[q]; }
+        if (valid) {
+            if (left) dst[lbase + lp + (uint32_t)__popcll(ml & lt)] = id;
+            else dst[rbase + rp + (uint32_t)__popcll(mr & lt)] = id;
+        }
+        lbase += lsum; rbase += rsum;
+        __syncthreads();
+    }
+}
+
+// One wave finishes the subtree of a node of <= kSmall references: the references' boxes live in LDS, `perm` holds their current
+// order, every node of the subtree is binned (LDS atomics), decided (select_split) and partitioned (ballots) by the 64 lanes.
+__global__ __launch_bounds__(256) void k_small(const Task* small, uint32_t ns, const uint32_t* order0, const uint32_t* order1, uint32_t* order_final, const float* ref_box,
+                                               Node2* node2, Counters* ctr, int max_leaf, float prim_cost) {
+    __shared__ uint32_t s_gid[4][kSmall];
+    __shared__ float s_box[4][6][kSmall];
+    __shared__ uint16_t s_perm[4][kSmall], s_perm2[4][kSmall];
+    __shared__ uint32_t s_mn[4][kBinWords], s_mx[4][kBinWords], s_cnt[4][96];
+    __shared__ Task s_stack[4][12];
+    const uint32_t w = threadIdx.x >> 6;
+    const uint32_t ti = blockIdx.x * 4u + w;
+    if (ti >= ns) return;
+    const int lane = lane_id();
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    uint32_t* gid = s_gid[w]; uint16_t* perm = s_perm[w]; uint16_t* perm2 = s_perm2[w];
+    uint32_t* bmn = s_mn[w]; uint32_t* bmx = s_mx[w]; uint32_t* bcnt = s_cnt[w];
+    Task cur = small[ti];
+    const uint32_t gfirst = cur.first;
+    PHASE_BEGIN();
+    {
+        const uint32_t* order = (cur.flags & kTaskBuf) ? order1 : order0;
+        for (uint32_t i = (uint32_t)lane; i < cur.count; i += 64u) {
+            const uint32_t id = order[gfirst + i];
+            gid[i] = id; perm[i] = (uint16_t)i;
+            float mn[3], mx[3]; load_box(ref_box, id, mn, mx);
+            for (int a = 0; a < 3; ++a) { s_box[w][a][i] = mn[a]; s_box[w][3 + a][i] = mx[a]; }
+        }
+    }
+    cur.first = 0; // local from here on
+    wave_sync();
+    PHASE(0);
+    int sp = 0; uint32_t splits = 0;
+    for (;;) {
+        bool done = false;
+        if (cur.count == 1u) {
+            if (lane == 0) { order_final[gfirst + cur.first] = gid[perm[cur.first]]; set_ref(node2, ctr, cur.parent, cur.flags, make_leaf_ref(gfirst + cur.first, 1u)); }
+            done = true;
+        } else {
+            for (uint32_t i = (uint32_t)lane; i < (uint32_t)kBinWords; i += 64u) { bmn[i] = 0xffffffffu; bmx[i] = 0u; }
+            for (uint32_t i = (uint32_t)lane; i < 96u; i += 64u) bcnt[i] = 0u;
+            wave_sync();
+            PHASE(1);
+            float scale[3]; bool use[3];
+            for (int a = 0; a < 3; ++a) { use[a] = cur.cmx[a] > cur.cmn[a]; scale[a] = use[a] ? (float)kSahBins / (cur.cmx[a] - cur.cmn[a]) : 0.0f; }
+            for (uint32_t i = (uint32_t)lane; i < cur.count; i += 64u) {
+                const uint32_t e = perm[cur.first + i];
+                float mn[3], mx[3], ce[3];
+                for (int a = 0; a < 3; ++a) { mn[a] = s_box[w][a][e]; mx[a] = s_box[w][3 + a][e]; ce[a] = 0.5f * mn[a] + 0.5f * mx[a]; }
+                for (int axis = 0; axis < 3; ++axis) {
+                    if (!use[axis]) continue;
+                    const int idx = axis * 32 + bin_of(ce[axis], cur.cmn[axis], scale[axis]);
+                    for (int a = 0; a < 3; ++a) {
+                        atomicMin(&bmn[idx * 6 + a], enc(mn[a])); atomicMin(&bmn[idx * 6 + 3 + a], enc(ce[a]));
+                        atomicMax(&bmx[idx * 6 + a], enc(mx[a])); atomicMax(&bmx[idx * 6 + 3 + a], enc(ce[a]));
+                    }
+                    atomicAdd(&bcnt[idx], 1u);
+                }
+            }
+            wave_sync();
+            PHASE(2);
+            SplitResult r;
+            select_split(bmn, bmx, bcnt, cur, max_leaf, prim_cost, r);
+            PHASE(3);
+            if (r.leaf) {
+                for (uint32_t i = (uint32_t)lane; i < cur.count; i += 64u) order_final[gfirst + cur.first + i] = gid[perm[cur.first + i]];
+                if (lane == 0) set_ref(node2, ctr, cur.parent, cur.flags, make_leaf_ref(gfirst + cur.first, cur.count));
+                done = true;
+            } else {
+                uint32_t mid; float L[12], R[12];
+                if (r.axis < 0) {
+                    mid = cur.first + cur.count / 2u;
+                    init12(L); init12(R);
+                    for (uint32_t i = (uint32_t)lane; i < cur.count; i += 64u) {
+                        const uint32_t e = perm[cur.first + i];
+                        float mn[3], mx[3];
+                        for (int a = 0; a < 3; ++a) { mn[a] = s_box[w][a][e]; mx[a] = s_box[w][3 + a][e]; }
+                        if (cur.first + i < mid) acc12(L, mn, mx); else acc12(R, mn, mx);
+                    }
+                    wave_reduce12(L); wave_reduce12(R);
+                } else {
+                    mid = cur.first + r.nleft;
+                    for (int a = 0; a < 3; ++a) {
+                        L[a] = r.lb_mn[a]; L[3 + a] = r.lc_mn[a]; L[6 + a] = r.lb_mx[a]; L[9 + a] = r.lc_mx[a];
+                        R[a] = r.rb_mn[a]; R[3 + a] = r.rc_mn[a]; R[6 + a] = r.rb_mx[a]; R[9 + a] = r.rc_mx[a];
+                    }
+                    // stable partition of perm[first, first + count) by bin <= split
+                    uint32_t l = 0, rr = 0;
+                    const float plo = cur.cmn[r.axis], pscale = (float)kSahBins / (cur.cmx[r.axis] - cur.cmn[r.axis]);
+                    for (uint32_t base = 0; base < cur.count; base += 64u) {
+                        const uint32_t i = base + (uint32_t)lane;
+                        const bool valid = i < cur.count;
+                        uint32_t e = 0; bool left = false;
+                        if (valid) {
+                            e = perm[cur.first + i];
+                            const float ce = 0.5f * s_box[w][r.axis][e] + 0.5f * s_box[w][3 + r.axis][e];
+                            left = bin_of(ce, plo, pscale) <= r.split;
+                        }
+                        const unsigned long long ml = __ballot(valid && left), mr = __ballot(valid && !left);
+                        if (valid) {
+                            if (left) perm2[cur.first + l + (uint32_t)__popcll(ml & lt)] = (uint16_t)e;
+                            else perm2[mid + rr + (uint32_t)__popcll(mr & lt)] = (uint16_t)e;
+                        }
+                        l += (uint32_t)__popcll(ml); rr += (uint32_t)__popcll(mr);
+                    }
+                    wave_sync();
+                    for (uint32_t i = (uint32_t)lane; i < cur.count; i += 64u) perm[cur.first + i] = perm2[cur.first + i];
+                    wave_sync();
+                }
+                PHASE(4);
+                const int32_t me = (int32_t)(gfirst + mid - 1u);
+                if (lane == 0) {
+                    Node2 n;
+                    for (int a = 0; a < 3; ++a) { n.lmin[a] = L[a]; n.lmax[a] = L[6 + a]; n.rmin[a] = R[a]; n.rmax[a] = R[6 + a]; }
+                    n.left = kEmptyChild; n.right = kEmptyChild;
+                    node2[me] = n;
+                    set_ref(node2, ctr, cur.parent, cur.flags, me);
+                }
+                ++splits;
+                Task lc, rc;
+                make_task(lc, cur.first, mid - cur.first, me, 0u, L, L + 6, L + 3, L + 9);
+                make_task(rc, mid, cur.first + cur.count - mid, me, kTaskSide, R, R + 6, R + 3, R + 9);
+                // the larger child waits on the stack (depth <= log2 kSmall), the smaller one is next
+                const bool left_first = lc.count <= rc.count;
+                if (lane == 0) s_stack[w][sp] = left_first ? rc : lc;
+                ++sp;
+                cur = left_first ? lc : rc;
+                wave_sync();
+            }
+        }
+        PHASE(5);
+        if (done) {
+            if (sp == 0) break;
+            --sp;
+            cur = s_stack[w][sp];
+            wave_sync();
+        }
+        PHASE(6);
+    }
+    PHASE_END(ctr);
+    if (lane == 0 && splits) atomicAdd(&ctr->n_binary, splits);
+}
+
+// ---- stage 4: collapse -------------------------------------------------------------------------------------------------
+struct Tmp4 { float mn[4][3], mx[4][3]; int32_t ref[4]; uint32_t n, size, dfs, broot; };
+static_assert(sizeof(Tmp4) == 128, "Tmp4 layout");
+
+// Level by level: node `id` (rooted at binary node tmp[id].broot) takes its root's two children and opens the internal child with
+// the largest box until four slots are used — Collapser::collapse of bvh_build.cpp — and hands out ids to its internal children.
+__global__ __launch_bounds__(256) void k_collapse_level(const Node2* node2, Tmp4* tmp, uint32_t start, uint32_t end, Counters* ctr) {
+    const uint32_t id = start + blockIdx.x * 256u + threadIdx.x;
+    const bool active = id < end;
+    float mn[4][3], mx[4][3]; int32_t ref[4]; int n = 0;
+    auto push_children = [&](int32_t node) {
+        const Node2 b = node2[node];
+        for (int a = 0; a < 3; ++a) { mn[n][a] = b.lmin[a]; mx[n][a] = b.lmax[a]; mn[n + 1][a] = b.rmin[a]; mx[n + 1][a] = b.rmax[a]; }
+        ref[n] = b.left; ref[n + 1] = b.right; n += 2;
+    };
+    uint32_t m = 0;
+    if (active) {
+        push_children((int32_t)tmp[id].broot);
+        while (n < 4) {
+            int best = -1; float ba = -1.f;
+            for (int k = 0; k < n; ++k) {
+                const float dx = mx[k][0] - mn[k][0], dy = mx[k][1] - mn[k][1], dz = mx[k][2] - mn[k][2];
+                const float ar = dx * dy + dy * dz + dz * dx;
+                if (ref[k] >= 0 && ar > ba) { ba = ar; best = k; }
+            }
+            if (best < 0) break;
+            const int32_t node = ref[best];
+            for (int k = best; k + 1 < n; ++k) { for (int a = 0; a < 3; ++a) { mn[k][a] = mn[k + 1][a]; mx[k][a] = mx[k + 1][a]; } ref[k] = ref[k + 1]; }
+            --n;
+            push_children(node);
+        }
+        for (int k = 0; k < n; ++k) m += ref[k] >= 0 ? 1u : 0u;
+    }
+    // ids of the internal children: one atomic per wave
+    uint32_t incl = m;
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, off, 64); if (lane_id() >= off) incl += o; }
+    const uint32_t total = bcast_u(incl, 63);
+    uint32_t base = 0;
+    if (lane_id() == 63 && total) base = atomicAdd(&ctr->next_id, total);
+    base = bcast_u(base, 63);
+    if (!active) return;
+    uint32_t child = base + incl - m;
+    Tmp4 out = tmp[id];
+    out.n = (uint32_t)n; out.size = 1u;
+    for (int k = 0; k < 4; ++k) {
+        if (k < n) {
+            for (int a = 0; a < 3; ++a) { out.mn[k][a] = mn[k][a]; out.mx[k][a] = mx[k][a]; }
+            if (ref[k] >= 0) { tmp[child].broot = (uint32_t)ref[k]; out.ref[k] = (int32_t)child; ++child; } else out.ref[k] = ref[k];
+        } else out.ref[k] = kEmptyChild;
+    }
+    tmp[id] = out;
+}
+__global__ __launch_bounds__(256) void k_sizes_level(Tmp4* tmp, uint32_t start, uint32_t end) {
+    const uint32_t id = start + blockIdx.x * 256u + threadIdx.x;
+    if (id >= end) return;
+    uint32_t s = 1u;
+    for (uint32_t k = 0; k < tmp[id].n; ++k) if (tmp[id].ref[k] >= 0) s += tmp[tmp[id].ref[k]].size;
+    tmp[id].size = s;
+}
+// Depth-first positions (parent, then the subtrees of its internal children in slot order: the host Collapser's order) and the final nodes.
+__global__ __launch_bounds__(256) void k_emit_level(Tmp4* tmp, uint32_t start, uint32_t end, BvhNode* out, int32_t node_base, uint32_t prim_base) {
+    const uint32_t id = start + blockIdx.x * 256u + threadIdx.x;
+    if (id >= end) return;
+    const Tmp4 t = tmp[id];
+    uint32_t run = t.dfs + 1u;
+    BvhNode nd;
+    const int lo_slot[3] = {0, 4, 3}, hi_slot[3] = {1, 6, 7};
+    const float big = 3.402823466e+38f;
+    for (int k = 0; k < 4; ++k) {
+        int32_t ref;
+        if (k < (int)t.n) {
+            for (int a = 0; a < 3; ++a) { nd.slot[lo_slot[a]][k] = t.mn[k][a]; nd.slot[hi_slot[a]][k] = t.mx[k][a]; }
+            if (t.ref[k] >= 0) { tmp[t.ref[k]].dfs = run; ref = (int32_t)run + node_base; run += tmp[t.ref[k]].size; }
+            else { const uint32_t v = (uint32_t)~t.ref[k]; ref = make_leaf_ref((v >> 3) + prim_base, (v & 7u) + 1u); }
+        } else {
+            for (int a = 0; a < 3; ++a) { nd.slot[lo_slot[a]][k] = big; nd.slot[hi_slot[a]][k] = -big; }
+            ref = kEmptyChild;
+        }
+        nd.slot[2][k] = __int_as_float(ref);
+        nd.slot[5][k] = 0.0f;
+    }
+    out[t.dfs] = nd;
+}
+
+// ---- stage 5 -------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gather(const uint32_t* order, const uint32_t* ref_tri, const TriRec* recs, const TriUv* uvs, uint32_t nrefs, TriRec* out_tris, TriUv* out_uvs) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= nrefs) return;
+    const uint32_t t = ref_tri[order[i]];
+    const float4* s = reinterpret_cast<const float4*>(recs + t);
+    float4* d = reinterpret_cast<float4*>(out_tris + i);
+    d[0] = s[0]; d[1] = s[1]; d[2] = s[2];
+    const float2* su = reinterpret_cast<const float2*>(uvs + t);
+    float2* du = reinterpret_cast<float2*>(out_uvs + i);
+    du[0] = su[0]; du[1] = su[1]; du[2] = su[2];
+}
+
+// ---- host side -------------------------------------------------------------------------------------------------------------
+struct Arena { // one allocation carved into 256-byte aligned pieces
+    char* base = nullptr; size_t size = 0, used = 0;
+    hipError_t reserve(size_t bytes) { size = bytes; used = 0; return hipMalloc((void**)&base, bytes); }
+    template <typename T> T* take(size_t n) { used = (used + 255u) & ~(size_t)255u; T* p = (T*)(base + used); used += n * sizeof(T); return used <= size ? p : nullptr; }
+    void release() { if (base) (void)hipFree(base); base = nullptr; }
+};
+template <typename T> size_t padded(size_t n) { return ((n * sizeof(T)) + 255u + 256u) & ~(size_t)255u; }
+
+struct Stopwatch {
+    bool on; std::chrono::steady_clock::time_point t0;
+    explicit Stopwatch(bool enabled) : on(enabled), t0(std::chrono::steady_clock::now()) {}
+    void lap(const char* what) {
+        if (!on) return;
+        (void)hipDeviceSynchronize();
+        auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "  device build: %s %.1f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
+
+#define DB_TRY(expr)                                                                                                     \
+    do {                                                                                                                 \
+        hipError_t e_ = (expr);                                                                                          \
+        if (e_ != hipSuccess) { err = std::string("device BLAS build: ") + #expr + ": " + hipGetErrorString(e_); return e_ == hipErrorOutOfMemory ? NRAYS_ERR_OOM : NRAYS_ERR_HIP; } \
+    } while (0)
+
+int build_impl(const std::vector<DeviceMeshPart>& parts, const DeviceBuildOptions& opt, int32_t node_base, uint32_t prim_base, DeviceBlas& out, std::string& err,
+               Arena& a1, Arena& a2, Arena& a3) {
+    const bool verbose = getenv("NRAYS_BUILD_TIMES") != nullptr;
+    Stopwatch sw(verbose);
+    size_t n = 0;
+    for (const DeviceMeshPart& p : parts) n += p.num_triangles;
+    if (n == 0 || n >= (1u << 28)) { err = "device BLAS build: bad triangle count"; return NRAYS_ERR_BAD_ARG; }
+    out.num_triangles = n;
+    const uint32_t nblocks_tri = [&] { uint32_t b = 0; for (const DeviceMeshPart& p : parts) b += (p.num_triangles + 255u) / 256u; return b; }();
+    const uint32_t split_grid = (uint32_t)std::min<size_t>(512, (n + 255) / 256);
+
+    // ---- phase 1: inputs, triangle records, pre-split counts ----
+    std::map<const void*, std::pair<size_t, void*>> uploads; // host array -> (bytes, device copy): meshes alias their vertex arrays
+    for (const DeviceMeshPart& p : parts) {
+        if (!p.vertices || !p.indices) { err = "device BLAS build: null mesh array"; return NRAYS_ERR_BAD_ARG; }
+        auto note = [&](const void* h, size_t bytes) { if (h) { auto& u = uploads[h]; u.first = std::max(u.first, bytes); u.second = nullptr; } };
+        note(p.vertices, (size_t)p.num_vertices * 24u); note(p.uvs, (size_t)p.num_vertices * 16u); note(p.indices, (size_t)p.num_triangles * 12u);
+    }
+    size_t bytes1 = 0;
+    for (auto& kv : uploads) bytes1 += padded<char>(kv.second.first);
+    bytes1 += padded<TriRec>(n) + padded<TriUv>(n) + padded<float>(6 * n) + 2 * padded<double>(nblocks_tri) + padded<Counters>(1) + 2 * padded<uint32_t>(n + 1) +
+              padded<uint32_t>(kHistBins) + padded<SplitFrame>((size_t)split_grid * 256u * (kSplitDepthMax + 1)) + (1u << 20);
+    DB_TRY(a1.reserve(bytes1));
+    sw.lap("allocation (phase 1)");
+    for (auto& kv : uploads) {
+        kv.second.second = a1.take<char>(kv.second.first);
+        DB_TRY(hipMemcpy(kv.second.second, kv.first, kv.second.first, hipMemcpyHostToDevice));
+    }
+    TriRec* recs = a1.take<TriRec>(n); TriUv* uvs = a1.take<TriUv>(n); float* tbox = a1.take<float>(6 * n);
+    double* part_area = a1.take<double>(nblocks_tri); double* part_tri2 = a1.take<double>(nblocks_tri);
+    Counters* ctr = a1.take<Counters>(1);
+    uint32_t* counts = a1.take<uint32_t>(n + 1); uint32_t* offsets = a1.take<uint32_t>(n + 1); uint32_t* hist = a1.take<uint32_t>(kHistBins);
+    SplitFrame* frames = a1.take<SplitFrame>((size_t)split_grid * 256u * (kSplitDepthMax + 1));
+    void* cub_tmp1 = a1.take<char>(1u << 19);
+    if (!frames || !cub_tmp1) { err = "device BLAS build: arena overflow (phase 1)"; return NRAYS_ERR_OOM; }
+    sw.lap("upload of the mesh arrays");
+    Counters h_ctr; std::memset(&h_ctr, 0, sizeof h_ctr);
+    for (int k = 0; k < 6; ++k) { h_ctr.bounds[k] = 0xffffffffu; h_ctr.bounds[6 + k] = 0u; }
+    h_ctr.root_ref = kEmptyChild;
+    DB_TRY(hipMemcpy(ctr, &h_ctr, sizeof h_ctr, hipMemcpyHostToDevice));
+    {
+        uint32_t tri_base = 0, block_base = 0;
+        for (const DeviceMeshPart& p : parts) {
+            if (p.num_triangles == 0) continue;
+            PartDev d; d.vertices = (const double*)uploads[p.vertices].second; d.uvs = p.uvs ? (const double*)uploads[p.uvs].second : nullptr;
+            d.indices = (const uint32_t*)uploads[p.indices].second; d.num_vertices = p.num_vertices; d.num_triangles = p.num_triangles; d.node_id = p.node_id; d.tri_base = tri_base;
+            const uint32_t nb = (p.num_triangles + 255u) / 256u;
+            hipLaunchKernelGGL(k_tri_records, dim3(nb), dim3(256), 0, 0, d, recs, uvs, tbox, part_area, part_tri2, block_base, ctr);
+            tri_base += p.num_triangles; block_base += nb;
+        }
+    }
+    DB_TRY(hipGetLastError());
+    DB_TRY(hipMemcpy(&h_ctr, ctr, sizeof h_ctr, hipMemcpyDeviceToHost));
+    if (h_ctr.err & 1u) { err = "triangle index out of range"; return NRAYS_ERR_BAD_ARG; }
+    if (h_ctr.err & 2u) { err = "mesh vertex coordinate is not exactly representable in f32 (see DESIGN.md: f32-exact mesh storage)"; return NRAYS_ERR_UNSUPPORTED; }
+    if (h_ctr.err & 4u) { err = "mesh uv is not exactly representable in f32"; return NRAYS_ERR_UNSUPPORTED; }
+    auto dec_host = [](uint32_t e) { uint32_t b = (e & 0x80000000u) ? (e & 0x7fffffffu) : ~e; float f; std::memcpy(&f, &b, 4); return f; };
+    for (int a = 0; a < 3; ++a) { out.mn[a] = dec_host(h_ctr.bounds[a]); out.mx[a] = dec_host(h_ctr.bounds[6 + a]); }
+    sw.lap("triangle records");
+
+    // pre-splitting: the rule and the constants of scene_build.cpp: presplit()
+    size_t nrefs = n; bool hairy = false; double thr = 0.0; bool do_split = false;
+    if (opt.presplit && n >= 64 && opt.budget > 0.0) {
+        std::vector<double> pa(nblocks_tri), pt(nblocks_tri);
+        DB_TRY(hipMemcpy(pa.data(), part_area, nblocks_tri * sizeof(double), hipMemcpyDeviceToHost));
+        DB_TRY(hipMemcpy(pt.data(), part_tri2, nblocks_tri * sizeof(double), hipMemcpyDeviceToHost));
+        double total_area = 0.0, total_tri2 = 0.0;
+        for (uint32_t b = 0; b < nblocks_tri; ++b) { total_area += pa[b]; total_tri2 += pt[b]; }
+        hairy = total_area > 0.0 && (total_area - total_tri2) > opt.hairy_emptiness * total_area;
+        const double min_gain = (hairy ? opt.min_gain_hairy : opt.min_gain) * total_area / (double)n;
+        const size_t budget = (size_t)((hairy ? opt.budget_hairy : opt.budget) * (double)n);
+        DB_TRY(hipMemset(hist, 0, kHistBins * sizeof(uint32_t)));
+        hipLaunchKernelGGL(k_presplit<kModeHist>, dim3(split_grid), dim3(256), 0, 0, recs, tbox, (uint32_t)n, min_gain, frames, counts, offsets, hist, (float*)nullptr, (uint32_t*)nullptr);
+        size_t tmp_bytes = 1u << 19;
+        DB_TRY(hipcub::DeviceScan::ExclusiveSum(cub_tmp1, tmp_bytes, counts, offsets, (int)(n + 1)));
+        uint32_t extra = 0;
+        DB_TRY(hipMemcpy(&extra, offsets + n, 4, hipMemcpyDeviceToHost));
+        thr = min_gain;
+        if ((size_t)extra > budget) { // the budget binds: the threshold is the empty area below which the budget-th largest split falls
+            std::vector<uint32_t> h(kHistBins);
+            DB_TRY(hipMemcpy(h.data(), hist, kHistBins * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            size_t cum = 0; uint32_t b = kHistBins;
+            while (b > 0 && cum + h[b - 1] <= budget) { cum += h[b - 1]; --b; } // bins >= b fit in the budget
+            uint32_t bits = b << kHistShift; float edge; std::memcpy(&edge, &bits, 4);
+            thr = std::max(min_gain, (double)edge);
+            // (float)gain rounds to nearest: a piece just below the edge may have been filed above it; `gain > thr` is what both passes below apply
+            hipLaunchKernelGGL(k_presplit<kModeCount>, dim3(split_grid), dim3(256), 0, 0, recs, tbox, (uint32_t)n, thr, frames, counts, offsets, hist, (float*)nullptr, (uint32_t*)nullptr);
+            tmp_bytes = 1u << 19;
+            DB_TRY(hipcub::DeviceScan::ExclusiveSum(cub_tmp1, tmp_bytes, counts, offsets, (int)(n + 1)));
+            DB_TRY(hipMemcpy(&extra, offsets + n, 4, hipMemcpyDeviceToHost));
+        }
+        nrefs = n + extra; do_split = extra > 0;
+    }
+    out.hairy = hairy;
+    if (nrefs + (size_t)prim_base >= (1u << 28)) { err = "too many triangles"; return NRAYS_ERR_UNSUPPORTED; }
+    sw.lap("pre-split counts");
+
+    // ---- phase 2: references, binary build ----
+    const uint32_t R = (uint32_t)nrefs;
+    const size_t max_t = R / (kSmall + 1u) + 2u, max_c = R / kChunk + max_t + 2u, small_cap = R / 8u + 1024u;
+    size_t bytes2 = padded<float>(6 * (size_t)R) + 3 * padded<uint32_t>(R) + padded<Node2>(R) + 2 * padded<Task>(max_t) + padded<Task>(small_cap) + 2 * padded<uint32_t>(max_t * kBinWords) +
+                    padded<uint32_t>(max_t * 96u) + padded<SplitInfo>(max_t) + padded<uint32_t>(max_t + 1) + 3 * padded<uint32_t>(max_c) + padded<uint32_t>(max_c * 96u) + (1u << 16);
+    DB_TRY(a2.reserve(bytes2));
+    sw.lap("allocation (phase 2)");
+    float* ref_box = a2.take<float>(6 * (size_t)R); uint32_t* ref_tri = a2.take<uint32_t>(R);
+    uint32_t* order0 = a2.take<uint32_t>(R); uint32_t* order1 = a2.take<uint32_t>(R);
+    Node2* node2 = a2.take<Node2>(R);
+    Task* tasks[2] = {a2.take<Task>(max_t), a2.take<Task>(max_t)}; Task* small = a2.take<Task>(small_cap);
+    uint32_t* gmn = a2.take<uint32_t>(max_t * kBinWords); uint32_t* gmx = a2.take<uint32_t>(max_t * kBinWords); uint32_t* gcnt = a2.take<uint32_t>(max_t * 96u);
+    SplitInfo* split = a2.take<SplitInfo>(max_t); uint32_t* chunk_base = a2.take<uint32_t>(max_t + 1);
+    uint32_t* chunk_task = a2.take<uint32_t>(max_c); uint32_t* chunk_off = a2.take<uint32_t>(max_c); uint32_t* scan_tmp = a2.take<uint32_t>(max_c);
+    uint32_t* chunk_cnt = a2.take<uint32_t>(max_c * 96u);
+    if (!chunk_cnt) { err = "device BLAS build: arena overflow (phase 2)"; return NRAYS_ERR_OOM; }
+    if (do_split) hipLaunchKernelGGL(k_presplit<kModeEmit>, dim3(split_grid), dim3(256), 0, 0, recs, tbox, (uint32_t)n, thr, frames, counts, offsets, hist, ref_box, ref_tri);
+    else hipLaunchKernelGGL(k_iota_refs, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, 0, (uint32_t)n, tbox, ref_box, ref_tri);
+    sw.lap("reference boxes");
+    const float prim_cost = hairy ? opt.prim_cost_hairy : opt.prim_cost;
+    const int max_leaf = std::min(std::max(opt.max_leaf, 1), 8);
+    for (int k = 0; k < 6; ++k) { h_ctr.bounds[k] = 0xffffffffu; h_ctr.bounds[6 + k] = 0u; }
+    h_ctr.n_next = h_ctr.n_small = h_ctr.overflow = h_ctr.n_binary = 0; h_ctr.root_ref = kEmptyChild;
+    DB_TRY(hipMemcpy(ctr, &h_ctr, sizeof h_ctr, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_root_bounds, dim3(std::min<uint32_t>(1024u, (R + 255u) / 256u)), dim3(256), 0, 0, ref_box, R, order0, ctr);
+    hipLaunchKernelGGL(k_root_task, dim3(1), dim3(1), 0, 0, tasks[0], small, R, ctr);
+    uint32_t nt = R > kSmall ? 1u : 0u; int cur = 0, levels = 0;
+    while (nt > 0) {
+        if (nt > max_t) { err = "device BLAS build: task list overflow"; return NRAYS_ERR_HIP; }
+        hipLaunchKernelGGL(k_chunk_scan, dim3(1), dim3(1024), 0, 0, tasks[cur], nt, chunk_base);
+        uint32_t nchunks = 0;
+        DB_TRY(hipMemcpy(&nchunks, chunk_base + nt, 4, hipMemcpyDeviceToHost));
+        if (nchunks == 0 || nchunks > max_c) { err = "device BLAS build: chunk list overflow"; return NRAYS_ERR_HIP; }
+        DB_TRY(hipMemsetAsync(gmn, 0xff, (size_t)nt * kBinWords * 4u, 0));
+        DB_TRY(hipMemsetAsync(gmx, 0, (size_t)nt * kBinWords * 4u, 0));
+        DB_TRY(hipMemsetAsync(gcnt, 0, (size_t)nt * 96u * 4u, 0));
+        DB_TRY(hipMemsetAsync(&ctr->n_next, 0, 4, 0));
+        hipLaunchKernelGGL(k_bin, dim3(nchunks), dim3(256), 0, 0, tasks[cur], nt, chunk_base, chunk_task, order0, order1, ref_box, gmn, gmx, gcnt, chunk_cnt);
+        hipLaunchKernelGGL(k_select, dim3((nt + 3u) / 4u), dim3(256), 0, 0, tasks[cur], nt, gmn, gmx, gcnt, split, tasks[cur ^ 1], small, (uint32_t)small_cap, node2, order0, order1, order0,
+                           ref_box, ctr, max_leaf, prim_cost);
+        hipLaunchKernelGGL(k_part_scan, dim3(1), dim3(1024), 0, 0, chunk_task, chunk_base, chunk_cnt, split, nchunks, chunk_off, scan_tmp);
+        hipLaunchKernelGGL(k_scatter, dim3(nchunks), dim3(256), 0, 0, tasks[cur], chunk_task, chunk_base, chunk_off, split, order0, order1, ref_box);
+        DB_TRY(hipMemcpy(&nt, &ctr->n_next, 4, hipMemcpyDeviceToHost));
+        cur ^= 1; ++levels;
+        if (levels > 4096) { err = "device BLAS build: the large-node phase does not end"; return NRAYS_ERR_HIP; }
+    }
+    DB_TRY(hipMemcpy(&h_ctr, ctr, sizeof h_ctr, hipMemcpyDeviceToHost));
+    if (h_ctr.overflow || h_ctr.n_small > small_cap) { err = "device BLAS build: small-node list overflow"; return NRAYS_ERR_HIP; }
+    if (verbose) fprintf(stderr, "  device build: %d large-node levels, %u small subtrees\n", levels, h_ctr.n_small);
+    sw.lap("large nodes");
+    if (h_ctr.n_small) hipLaunchKernelGGL(k_small, dim3((h_ctr.n_small + 3u) / 4u), dim3(256), 0, 0, small, h_ctr.n_small, order0, order1, order0, ref_box, node2, ctr, max_leaf, prim_cost);
+    DB_TRY(hipGetLastError());
+    DB_TRY(hipMemcpy(&h_ctr, ctr, sizeof h_ctr, hipMemcpyDeviceToHost));
+#ifdef NR_BUILD_PHASES
+    fprintf(stderr, "  k_small wave cycles: load %llu, clear %llu, bin %llu, select %llu, partition %llu, node+leaf writes %llu, pop %llu\n", h_ctr.phase[0], h_ctr.phase[1], h_ctr.phase[2],
+            h_ctr.phase[3], h_ctr.phase[4], h_ctr.phase[5], h_ctr.phase[6]);
+#endif
+    sw.lap("small subtrees");
+
+    // ---- phase 3: collapse, layout, gather ----
+    DB_TRY(hipMalloc((void**)&out.tris, (size_t)R * sizeof(TriRec)));
+    DB_TRY(hipMalloc((void**)&out.uvs, (size_t)R * sizeof(TriUv)));
+    out.num_refs = R;
+    hipLaunchKernelGGL(k_gather, dim3((R + 255u) / 256u), dim3(256), 0, 0, order0, ref_tri, recs, uvs, R, out.tris, out.uvs);
+    if (h_ctr.root_ref < 0) { // a single leaf
+        const uint32_t v = (uint32_t)~h_ctr.root_ref;
+        out.root = h_ctr.root_ref == kEmptyChild ? kEmptyChild : make_leaf_ref((v >> 3) + prim_base, (v & 7u) + 1u);
+        if (h_ctr.root_ref == kEmptyChild) { err = "device BLAS build: no root"; return NRAYS_ERR_HIP; }
+        out.num_nodes = 0; out.max_depth = 0;
+        DB_TRY(hipDeviceSynchronize());
+        return NRAYS_OK;
+    }
+    const uint32_t nb = h_ctr.n_binary;
+    DB_TRY(a3.reserve(padded<Tmp4>(nb) + 4096));
+    Tmp4* tmp = a3.take<Tmp4>(nb);
+    {
+        Tmp4 root; std::memset(&root, 0, sizeof root); root.broot = (uint32_t)h_ctr.root_ref; root.dfs = 0;
+        DB_TRY(hipMemcpy(tmp, &root, sizeof root, hipMemcpyHostToDevice));
+        uint32_t one = 1; DB_TRY(hipMemcpy(&ctr->next_id, &one, 4, hipMemcpyHostToDevice));
+    }
+    std::vector<uint32_t> level_start{0u};
+    uint32_t end = 1;
+    while (level_start.back() < end) {
+        const uint32_t s = level_start.back();
+        hipLaunchKernelGGL(k_collapse_level, dim3((end - s + 255u) / 256u), dim3(256), 0, 0, node2, tmp, s, end, ctr);
+        level_start.push_back(end);
+        DB_TRY(hipMemcpy(&end, &ctr->next_id, 4, hipMemcpyDeviceToHost));
+        if (end > nb) { err = "device BLAS build: more 4-wide nodes than binary nodes"; return NRAYS_ERR_HIP; }
+        if (level_start.size() > 4096) { err = "device BLAS build: the collapse does not end"; return NRAYS_ERR_HIP; }
+    }
+    level_start.pop_back(); // the last entry opened an empty level
+    const uint32_t n4 = end;
+    for (size_t l = level_start.size(); l-- > 0;) {
+        const uint32_t s = level_start[l], e = l + 1 < level_start.size() ? level_start[l + 1] : n4;
+        if (e > s) hipLaunchKernelGGL(k_sizes_level, dim3((e - s + 255u) / 256u), dim3(256), 0, 0, tmp, s, e);
+    }
+    DB_TRY(hipMalloc((void**)&out.nodes, (size_t)n4 * sizeof(BvhNode)));
+    out.num_nodes = n4;
+    for (size_t l = 0; l < level_start.size(); ++l) {
+        const uint32_t s = level_start[l], e = l + 1 < level_start.size() ? level_start[l + 1] : n4;
+        if (e > s) hipLaunchKernelGGL(k_emit_level, dim3((e - s + 255u) / 256u), dim3(256), 0, 0, tmp, s, e, out.nodes, node_base, prim_base);
+    }
+    out.root = node_base; // the root of the collapse is node 0 of this BLAS
+    out.max_depth = (int)level_start.size() - 1;
+    DB_TRY(hipGetLastError());
+    DB_TRY(hipDeviceSynchronize());
+    if (verbose) fprintf(stderr, "  device build: %zu triangles, %u refs%s, %u binary nodes, %u 4-wide nodes, depth %d\n", n, R, hairy ? ", hair-like" : "", nb, n4, out.max_depth);
+    sw.lap("collapse + layout + gather");
+    return NRAYS_OK;
+}
+
+} // namespace
+
+int build_blas_device(const std::vector<DeviceMeshPart>& parts, const DeviceBuildOptions& opt, int32_t node_base, uint32_t prim_base, DeviceBlas& out, std::string& err) {
+    Arena a1, a2, a3;
+    int rc = build_impl(parts, opt, node_base, prim_base, out, err, a1, a2, a3);
+    (void)hipDeviceSynchronize();
+    a1.release(); a2.release(); a3.release();
+    if (rc != NRAYS_OK) { free_device_blas(out); (void)hipGetLastError(); }
+    return rc;
+}
+
+void free_device_blas(DeviceBlas& b) {
+    if (b.nodes) (void)hipFree(b.nodes);
+    if (b.tris) (void)hipFree(b.tris);
+    if (b.uvs) (void)hipFree(b.uvs);
+    b.nodes = nullptr; b.tris = nullptr; b.uvs = nullptr; b.num_nodes = 0; b.num_refs = 0;
+}
+
+} // namespace nrays

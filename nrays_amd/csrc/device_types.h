@@ -54,7 +54,9 @@ enum InstanceFlags : uint32_t {
     kInstHasUv = 8u,         // the mesh(es) behind this BLAS carry uvs
     kInstNoXform = 16u,      // identity rotation AND zero translation: local space == world space
     kInstNoUvValues = 32u,   // the node's material never reads the VALUES of u, v (NormalMaterial, untextured Phong): a ball skips atan2 / asin
-    kInstIncoherent = 64u    // hair-like mesh (scene_build.cpp: presplit): neighbouring rays walk different nodes (DScene::incoherent)
+    kInstIncoherent = 64u,   // hair-like mesh (scene_build.cpp: presplit): neighbouring rays walk different nodes (DScene::incoherent)
+    kInstDeviceTmp = 0x80000000u // host-side only, while a scene is being flattened: the BLAS was built on the device (bvh_device.hip) and
+                             // its root already addresses the final arrays; cleared before the instance is uploaded
 };
 
 // Flags carried in the 3 low bits of a TLAS leaf ref (triangle leaves use them as count - 1).

@@ -769,6 +769,24 @@ static int upload(NraysScene* sc, const std::vector<T>& v, const T** out) {
     return NRAYS_OK;
 }
 
+// Device-built segments first (device-to-device), then the host-built part: the layout HostScene's refs address.
+template <typename T>
+static int upload_joined(NraysScene* sc, const std::vector<std::pair<const T*, size_t>>& segs, const std::vector<T>& v, const T** out) {
+    *out = nullptr;
+    size_t total = v.size();
+    for (const auto& s : segs) total += s.second;
+    if (total == 0) return NRAYS_OK;
+    void* p = nullptr;
+    HIP_TRY(hipMalloc(&p, total * sizeof(T)));
+    sc->allocs.push_back(p);
+    sc->scene_bytes += total * sizeof(T);
+    size_t at = 0;
+    for (const auto& s : segs) { if (s.second) HIP_TRY(hipMemcpy((T*)p + at, s.first, s.second * sizeof(T), hipMemcpyDeviceToDevice)); at += s.second; }
+    if (!v.empty()) HIP_TRY(hipMemcpy((T*)p + at, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = (const T*)p;
+    return NRAYS_OK;
+}
+
 static int ensure_queue(NraysScene* sc, uint32_t capacity) {
     if (capacity <= sc->queue_capacity) return NRAYS_OK;
     for (int k = 0; k < 2; ++k) {
@@ -1250,9 +1268,15 @@ int nrays_scene_create(const NraysSceneDesc* desc, NraysScene** out_scene) {
     HostScene& h = sc->host;
     const auto t_create1 = std::chrono::steady_clock::now();
     std::memset(&sc->d, 0, sizeof sc->d);
-    if ((rc = upload(sc, h.nodes, &sc->d.nodes)) != NRAYS_OK) return bail(rc);
-    if ((rc = upload(sc, h.tris, &sc->d.tris)) != NRAYS_OK) return bail(rc);
-    if ((rc = upload(sc, h.triuvs, &sc->d.triuvs)) != NRAYS_OK) return bail(rc);
+    {
+        std::vector<std::pair<const BvhNode*, size_t>> nseg; std::vector<std::pair<const TriRec*, size_t>> tseg; std::vector<std::pair<const TriUv*, size_t>> useg;
+        for (const nrays::DeviceBlas& b : h.dev_blas) { nseg.push_back({b.nodes, b.num_nodes}); tseg.push_back({b.tris, b.num_refs}); useg.push_back({b.uvs, b.num_refs}); }
+        if ((rc = upload_joined(sc, nseg, h.nodes, &sc->d.nodes)) != NRAYS_OK) return bail(rc);
+        if ((rc = upload_joined(sc, tseg, h.tris, &sc->d.tris)) != NRAYS_OK) return bail(rc);
+        if ((rc = upload_joined(sc, useg, h.triuvs, &sc->d.triuvs)) != NRAYS_OK) return bail(rc);
+        for (nrays::DeviceBlas& b : h.dev_blas) nrays::free_device_blas(b);
+        h.dev_blas.clear();
+    }
     if ((rc = upload(sc, h.instances, &sc->d.instances)) != NRAYS_OK) return bail(rc);
     if ((rc = upload(sc, h.shadow_instances, &sc->d.shadow_instances)) != NRAYS_OK) return bail(rc);
     if ((rc = upload(sc, h.links, &sc->d.links)) != NRAYS_OK) return bail(rc);
@@ -1278,7 +1302,7 @@ int nrays_scene_create(const NraysSceneDesc* desc, NraysScene** out_scene) {
         if (h.shade_alpha_tex[i] >= 0) h.shade[i].alpha_tex.texels = trecs[h.shade_alpha_tex[i]].texels;
     }
     if ((rc = upload(sc, h.shade, &sc->d.shade)) != NRAYS_OK) return bail(rc);
-    if (getenv("NRAYS_BUILD_TIMES") && h.tris.size() > 1000000)
+    if (getenv("NRAYS_BUILD_TIMES") && h.tris.size() + h.dev_tris > 1000000)
         fprintf(stderr, "  nrays_scene_create: build_host_scene %.2f s, uploads %.2f s\n", std::chrono::duration<double>(t_create1 - t_create0).count(),
                 std::chrono::duration<double>(std::chrono::steady_clock::now() - t_create1).count());
     sc->d.closest_root = h.closest_root; sc->d.shadow_root = h.shadow_root;
@@ -1417,6 +1441,7 @@ void nrays_scene_destroy(NraysScene* sc) {
     (void)hipSetDevice(sc->device);
     if (sc->have_last) (void)hipStreamSynchronize(sc->last_stream);
     for (void* p : sc->allocs) (void)hipFree(p);
+    for (nrays::DeviceBlas& b : sc->host.dev_blas) nrays::free_device_blas(b); // a creation that failed between the build and the upload
     for (int k = 0; k < 2; ++k) if (sc->queue[k].block) (void)hipFree(sc->queue[k].block);
     for (int k = 0; k < 2; ++k) {
         if (sc->d_counts_set[k]) (void)hipFree(sc->d_counts_set[k]);
@@ -1605,6 +1630,21 @@ int nrays_render_rgb8(NraysScene* sc, const NraysRenderParams* p, uint8_t* out_r
 int nrays_debug_scene_flags(const NraysScene* sc, uint32_t out[2]) {
     if (!sc || !out) return fail(NRAYS_ERR_BAD_ARG, "null argument");
     out[0] = (uint32_t)sc->host.features; out[1] = sc->d.incoherent;
+    return NRAYS_OK;
+}
+
+int nrays_debug_blas_build(const NraysMesh* mesh, uint32_t flags, NraysBlasDump* out) {
+    if (!mesh || !out) return fail(NRAYS_ERR_BAD_ARG, "null argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(NRAYS_ERR_NO_DEVICE, "no HIP device visible");
+    nrays::BlasProbe probe; std::string err;
+    const int rc = nrays::build_blas_probe(mesh, (flags & 1u) != 0, (flags & 2u) == 0, probe, err);
+    if (rc != NRAYS_OK) return fail(rc, err);
+    out->num_nodes = (uint32_t)probe.nodes.size(); out->num_refs = (uint32_t)probe.tri_ids.size();
+    out->root = probe.root; out->max_depth = probe.max_depth; out->hairy = probe.hairy ? 1u : 0u;
+    if (probe.nodes.size() > out->node_capacity || probe.tri_ids.size() > out->ref_capacity) return fail(NRAYS_ERR_BAD_ARG, "dump buffers too small");
+    if (!probe.nodes.empty()) { if (!out->nodes) return fail(NRAYS_ERR_BAD_ARG, "null node buffer"); std::memcpy(out->nodes, probe.nodes.data(), probe.nodes.size() * sizeof(nrays::BvhNode)); }
+    if (!probe.tri_ids.empty()) { if (!out->tri_ids) return fail(NRAYS_ERR_BAD_ARG, "null reference buffer"); std::memcpy(out->tri_ids, probe.tri_ids.data(), probe.tri_ids.size() * 4u); }
     return NRAYS_OK;
 }
 

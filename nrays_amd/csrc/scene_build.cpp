@@ -1,6 +1,8 @@
 // scene_build.cpp — NraysSceneDesc -> HostScene (see scene_build.h).
 #include "scene_build.h"
 
+#include <hip/hip_runtime.h>
+
 #include <algorithm>
 #include <chrono>
 #include <future>
@@ -13,6 +15,8 @@
 #include <map>
 
 #include "bvh_build.h"
+#include "bvh_device.h"
+#include "presplit_clip.h"
 
 namespace nrays {
 namespace {
@@ -129,6 +133,7 @@ struct Blas {
     int32_t root;
     float mn[3], mx[3]; // local bounds
     bool hairy;         // thin diagonal triangles throughout (presplit())
+    bool device = false; // built by bvh_device.hip: root / leaf refs already address the scene's final arrays
 };
 
 // ---- triangle pre-splitting ----------------------------------------------------------------------
@@ -149,64 +154,12 @@ struct Blas {
 #ifndef NR_PRESPLIT_MINGAIN
 #define NR_PRESPLIT_MINGAIN 0.5 // a piece is split while its empty box area exceeds this fraction of the average box area
 #endif
-// A triangle clipped to a box is a convex polygon of at most 9 vertices (3 + one per box face).
-constexpr int kClipMax = 12;
-struct ClipPoly { double v[kClipMax][3]; int n; };
-// Sutherland-Hodgman against one axis plane; returns false (and an unusable polygon) if the vertex budget is exceeded.
-static bool clip_half(const ClipPoly& in, int axis, double c, bool keep_low, ClipPoly& out) {
-    out.n = 0;
-    for (int k = 0; k < in.n; ++k) {
-        const double* a = in.v[k];
-        const double* b = in.v[(k + 1) % in.n];
-        bool ia = keep_low ? a[axis] <= c : a[axis] >= c, ib = keep_low ? b[axis] <= c : b[axis] >= c;
-        if (ia) {
-            if (out.n >= kClipMax) return false;
-            for (int d = 0; d < 3; ++d) out.v[out.n][d] = a[d];
-            ++out.n;
-        }
-        if (ia != ib) {
-            if (out.n >= kClipMax) return false;
-            double t = (c - a[axis]) / (b[axis] - a[axis]);
-            for (int d = 0; d < 3; ++d) out.v[out.n][d] = d == axis ? c : a[d] + (b[d] - a[d]) * t;
-            ++out.n;
-        }
-    }
-    return true;
-}
-static PrimBounds poly_box(const ClipPoly& p, const PrimBounds& within) {
-    PrimBounds b;
-    for (int a = 0; a < 3; ++a) {
-        double lo = std::numeric_limits<double>::infinity(), hi = -lo;
-        for (int k = 0; k < p.n; ++k) { lo = std::min(lo, p.v[k][a]); hi = std::max(hi, p.v[k][a]); }
-        // outward f32 rounding + one ulp for the rounding of the clip itself; never larger than the box being split
-        b.mn[a] = std::max(within.mn[a], std::nextafterf(round_down_f32(lo), -std::numeric_limits<float>::infinity()));
-        b.mx[a] = std::min(within.mx[a], std::nextafterf(round_up_f32(hi), std::numeric_limits<float>::infinity()));
-    }
-    return b;
-}
-static double box_half_area(const PrimBounds& b) {
-    double dx = (double)b.mx[0] - b.mn[0], dy = (double)b.mx[1] - b.mn[1], dz = (double)b.mx[2] - b.mn[2];
-    return dx * dy + dy * dz + dz * dx;
-}
-static double poly_area2(const ClipPoly& p) { // twice the area of a planar convex polygon (fan from vertex 0)
-    double s = 0.0;
-    for (int k = 1; k + 1 < p.n; ++k) {
-        double e1[3], e2[3];
-        for (int d = 0; d < 3; ++d) { e1[d] = p.v[k][d] - p.v[0][d]; e2[d] = p.v[k + 1][d] - p.v[0][d]; }
-        double cx = e1[1] * e2[2] - e1[2] * e2[1], cy = e1[2] * e2[0] - e1[0] * e2[2], cz = e1[0] * e2[1] - e1[1] * e2[0];
-        s += std::sqrt(cx * cx + cy * cy + cz * cz);
-    }
-    return s;
-}
 // refs_box / refs_tri: one entry per reference (initially one per triangle), grown in place.  Candidates are pieces
 //   (a) whose box is at least NR_PRESPLIT_EMPTY empty (1 - 2 area / half box area: thin diagonal primitives; a large
 //       axis-aligned wall triangle has emptiness 0 and is never split, whatever its size), and
 //   (b) whose empty box area exceeds NR_PRESPLIT_MINGAIN times the average box area of the mesh;
 // they are split in order of decreasing empty area (a heap) until the budget of NR_PRESPLIT_BUDGET extra references
 // per triangle is used up, so a tight budget goes to the worst offenders first.
-#ifndef NR_PRESPLIT_EMPTY
-#define NR_PRESPLIT_EMPTY 0.5
-#endif
 #ifndef NR_PRESPLIT_HAIRY
 #define NR_PRESPLIT_HAIRY 0.9        // area-weighted emptiness of the mesh above which it counts as hair-like
 #endif
@@ -219,22 +172,6 @@ static double poly_area2(const ClipPoly& p) { // twice the area of a planar conv
 #ifndef NR_PRESPLIT_MINGAIN_HAIRY
 #define NR_PRESPLIT_MINGAIN_HAIRY 0.05
 #endif
-static void tri_poly(const TriRec& r, ClipPoly& p) {
-    p.n = 3;
-    const float* vs[3] = {r.v0, r.v1, r.v2};
-    for (int k = 0; k < 3; ++k) for (int d = 0; d < 3; ++d) p.v[k][d] = vs[k][d];
-}
-// One midpoint split of a piece; false if the piece cannot be split (degenerate clip, vertex budget, empty box).
-static bool split_piece(const ClipPoly& poly, const PrimBounds& box, ClipPoly& lo, ClipPoly& hi, PrimBounds& bl, PrimBounds& bh) {
-    int axis = 0; float ext = box.mx[0] - box.mn[0];
-    for (int a = 1; a < 3; ++a) if (box.mx[a] - box.mn[a] > ext) { ext = box.mx[a] - box.mn[a]; axis = a; }
-    const double mid = 0.5 * ((double)box.mn[axis] + (double)box.mx[axis]);
-    if (!clip_half(poly, axis, mid, true, lo) || !clip_half(poly, axis, mid, false, hi)) return false;
-    if (lo.n < 3 || hi.n < 3) return false; // the plane misses the piece (degenerate): leave it alone
-    bl = poly_box(lo, box); bh = poly_box(hi, box);
-    for (int a = 0; a < 3; ++a) if (!(bl.mn[a] <= bl.mx[a]) || !(bh.mn[a] <= bh.mx[a])) return false;
-    return true;
-}
 // The exact procedure: pieces split in order of decreasing empty area until the budget is used up.  `tris` lists the
 // triangles taking part (all of them, or a sample); boxes[k] / owner[k] describe reference k (k < tris.size(): the
 // k-th listed triangle).  Returns the empty area of the last piece split (the threshold the budget amounts to), or
@@ -339,8 +276,53 @@ static bool presplit(const std::vector<TriRec>& recs, std::vector<PrimBounds>& r
 }
 
 // Appends a BLAS over the triangles of `node_ids` (TriMesh nodes sharing one isometry).
-int append_blas(const NraysSceneDesc* d, const std::vector<uint32_t>& node_ids, HostScene& out, Blas& blas, std::string& err) {
+#ifndef NR_MAX_LEAF
+#define NR_MAX_LEAF 8
+#endif
+// Triangle count from which a BLAS is built on the GPU (bvh_device.hip); NRAYS_GPU_BUILD=0: never, NRAYS_GPU_BUILD_MIN=n: from n triangles.
+// Below ~50 k triangles the host builder's few milliseconds are less than the device path's allocations and round trips.
+static size_t device_build_min() { // read per scene (not cached): tests and A/B runs flip it between two nrays_scene_create calls
+    if (const char* e = getenv("NRAYS_GPU_BUILD")) if (atoi(e) == 0) return std::numeric_limits<size_t>::max();
+    if (const char* e = getenv("NRAYS_GPU_BUILD_MIN")) return (size_t)std::max(1ll, atoll(e));
+    return (size_t)50000;
+}
+static DeviceBuildOptions device_options(bool presplit_on) {
+    DeviceBuildOptions o;
+    o.max_leaf = NR_MAX_LEAF; o.prim_cost = NR_PRIM_COST; o.prim_cost_hairy = NR_PRIM_COST_HAIRY;
+    o.budget = NR_PRESPLIT_BUDGET; o.budget_hairy = NR_PRESPLIT_BUDGET_HAIRY; o.min_gain = NR_PRESPLIT_MINGAIN; o.min_gain_hairy = NR_PRESPLIT_MINGAIN_HAIRY;
+    o.hairy_emptiness = NR_PRESPLIT_HAIRY; o.presplit = presplit_on;
+    return o;
+}
+
+// which: 0 = by size (device_build_min), 1 = host builder, 2 = device builder
+int append_blas(const NraysSceneDesc* d, const std::vector<uint32_t>& node_ids, HostScene& out, Blas& blas, std::string& err, int which = 0, bool presplit_on = true) {
     const auto TA = std::chrono::steady_clock::now();
+    {
+        size_t total = 0;
+        for (uint32_t ni : node_ids) total += d->meshes[d->nodes[ni].mesh_id].num_triangles;
+        if (which == 2 || (which == 0 && total >= device_build_min())) {
+            std::vector<DeviceMeshPart> parts;
+            for (uint32_t ni : node_ids) {
+                const NraysMesh& m = d->meshes[d->nodes[ni].mesh_id];
+                parts.push_back(DeviceMeshPart{m.vertices, m.uvs, m.indices, m.num_vertices, m.num_triangles, ni});
+            }
+            DeviceBlas db;
+            const int rc = build_blas_device(parts, device_options(presplit_on), (int32_t)out.dev_nodes, (uint32_t)out.dev_tris, db, err);
+            if (getenv("NRAYS_BUILD_TIMES")) fprintf(stderr, "device BLAS build %.3f s (%zu triangles, %zu refs%s)%s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - TA).count(),
+                                                     total, db.num_refs, db.hairy ? ", hair-like" : "", rc == NRAYS_OK ? "" : " FAILED");
+            if (rc == NRAYS_OK) {
+                blas.root = db.root; blas.hairy = db.hairy; blas.device = true;
+                for (int a = 0; a < 3; ++a) { blas.mn[a] = db.mn[a]; blas.mx[a] = db.mx[a]; }
+                out.max_bvh_depth = std::max(out.max_bvh_depth, db.max_depth);
+                out.dev_nodes += db.num_nodes; out.dev_tris += db.num_refs;
+                out.dev_blas.push_back(db);
+                return NRAYS_OK;
+            }
+            if (rc == NRAYS_ERR_BAD_ARG || rc == NRAYS_ERR_UNSUPPORTED || which == 2) return rc; // the caller's data, or a probe of the device builder itself
+            fprintf(stderr, "nrays: %s; building this BLAS on the host\n", err.c_str()); // an internal limit of the device builder: the host builder takes over
+            err.clear();
+        }
+    }
     std::vector<PrimBounds> pb;
     std::vector<TriRec> recs;
     std::vector<TriUv> uvs;
@@ -379,13 +361,10 @@ int append_blas(const NraysSceneDesc* d, const std::vector<uint32_t>& node_ids, 
     }
     for (int a = 0; a < 3; ++a) { blas.mn[a] = std::numeric_limits<float>::infinity(); blas.mx[a] = -std::numeric_limits<float>::infinity(); }
     for (const PrimBounds& b : pb) for (int a = 0; a < 3; ++a) { blas.mn[a] = std::min(blas.mn[a], b.mn[a]); blas.mx[a] = std::max(blas.mx[a], b.mx[a]); }
-#ifndef NR_MAX_LEAF
-#define NR_MAX_LEAF 8
-#endif
     std::vector<uint32_t> ref_tri(recs.size());
     for (size_t k = 0; k < ref_tri.size(); ++k) ref_tri[k] = (uint32_t)k;
     auto T0 = std::chrono::steady_clock::now();
-    const bool hairy = presplit(recs, pb, ref_tri); // pb becomes one box per REFERENCE
+    const bool hairy = presplit_on && presplit(recs, pb, ref_tri); // pb becomes one box per REFERENCE
     auto T1 = std::chrono::steady_clock::now();
     // thin tubes: a leaf's triangles mostly miss, and a node visit is cheap — leaves split sooner (hairball 2.96 -> 2.91 ms; the
     // architectural stand-in is 4 % slower with this value, profiles/r02_nodeloop_ab.log)
@@ -409,6 +388,7 @@ int append_blas(const NraysSceneDesc* d, const std::vector<uint32_t>& node_ids, 
     out.nodes.insert(out.nodes.end(), bvh.nodes.begin(), bvh.nodes.end());
     blas.root = bvh.root;
     blas.hairy = hairy;
+    blas.device = false; // (the caller may hand in the Blas of an earlier, device-built group)
     if (getenv("NRAYS_BUILD_TIMES") && recs.size() > 1000000) fprintf(stderr, "  append_blas: after the build (rebase, gather, node copy) %.2f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - T2).count());
     return NRAYS_OK;
 }
@@ -437,6 +417,32 @@ int32_t append_tlas(std::vector<Instance>& insts, const std::vector<PrimBounds>&
 }
 
 } // namespace
+
+int build_blas_probe(const NraysMesh* mesh, bool device, bool presplit_on, BlasProbe& out, std::string& err) {
+    if (!mesh || !mesh->vertices || !mesh->indices || mesh->num_triangles == 0) { err = "bad mesh"; return NRAYS_ERR_BAD_ARG; }
+    NraysNode node; std::memset(&node, 0, sizeof node);
+    node.shape_kind = NRAYS_SHAPE_TRIMESH; node.mesh_id = 0;
+    NraysSceneDesc d; std::memset(&d, 0, sizeof d);
+    d.meshes = mesh; d.num_meshes = 1; d.nodes = &node; d.num_nodes = 1;
+    HostScene hs; Blas blas;
+    const int rc = append_blas(&d, std::vector<uint32_t>{0u}, hs, blas, err, device ? 2 : 1, presplit_on);
+    if (rc != NRAYS_OK) { for (DeviceBlas& b : hs.dev_blas) free_device_blas(b); return rc; }
+    out.root = blas.root; out.hairy = blas.hairy; out.max_depth = hs.max_bvh_depth;
+    if (device) {
+        DeviceBlas& b = hs.dev_blas[0];
+        out.nodes.resize(b.num_nodes);
+        std::vector<TriRec> tris(b.num_refs);
+        bool ok = (b.num_nodes == 0 || hipMemcpy(out.nodes.data(), b.nodes, b.num_nodes * sizeof(BvhNode), hipMemcpyDeviceToHost) == hipSuccess) &&
+                  hipMemcpy(tris.data(), b.tris, b.num_refs * sizeof(TriRec), hipMemcpyDeviceToHost) == hipSuccess;
+        free_device_blas(b);
+        if (!ok) { err = "copy of the device-built BLAS failed"; return NRAYS_ERR_HIP; }
+        for (const TriRec& r : tris) out.tri_ids.push_back(r.tri_id);
+    } else {
+        out.nodes = hs.nodes;
+        for (const TriRec& r : hs.tris) out.tri_ids.push_back(r.tri_id);
+    }
+    return NRAYS_OK;
+}
 
 int build_host_scene(const NraysSceneDesc* d, HostScene& out, std::string& err) {
     if (!d) { err = "null scene descriptor"; return NRAYS_ERR_BAD_ARG; }
@@ -599,6 +605,7 @@ int build_host_scene(const NraysSceneDesc* d, HostScene& out, std::string& err) 
             in.flags &= ~(uint32_t)kInstSolid; // TriMesh ignores `solid` (SURVEY B-8)
             in.node_id = sub.size() == 1 ? (int32_t)sub[0] : -1;
             in.blas_root = blas.root;
+            if (blas.device) in.flags |= kInstDeviceTmp;
             if (blas.hairy) { in.flags |= kInstIncoherent; out.any_incoherent = true; }
             double c[3], h[3];
             for (int a = 0; a < 3; ++a) { c[a] = 0.5 * ((double)blas.mn[a] + (double)blas.mx[a]); h[a] = 0.5 * ((double)blas.mx[a] - (double)blas.mn[a]); }
@@ -633,6 +640,7 @@ int build_host_scene(const NraysSceneDesc* d, HostScene& out, std::string& err) 
         if (!(d->num_lights == 1 && d->lights[0].racsample == 1)) f |= 16; // more than one light sample per hit
         out.features = f;
     }
+    const size_t host_blas_nodes = out.nodes.size(); // what follows are TLAS nodes
     out.bounded = planes_c.empty();
     for (int a = 0; a < 3; ++a) { out.bounds_mn[a] = std::numeric_limits<float>::infinity(); out.bounds_mx[a] = -std::numeric_limits<float>::infinity(); }
     for (const PrimBounds& b : cbox) for (int a = 0; a < 3; ++a) { out.bounds_mn[a] = std::min(out.bounds_mn[a], b.mn[a]); out.bounds_mx[a] = std::max(out.bounds_mx[a], b.mx[a]); }
@@ -642,12 +650,27 @@ int build_host_scene(const NraysSceneDesc* d, HostScene& out, std::string& err) 
         out.planes.push_back((int32_t)cinst.size()); cinst.push_back(planes_c[k]);
         out.shadow_planes.push_back((int32_t)sinst.size()); sinst.push_back(planes_s[k]);
     }
+    if (out.dev_nodes || out.dev_tris) {
+        // Device-built BLASes come FIRST in the scene's node / triangle arrays (their refs were absolute from the start); everything the
+        // host built moves behind them: BLAS nodes (child and leaf refs), TLAS nodes (child refs; their leaves are instance indices), roots.
+        const int32_t dn = (int32_t)out.dev_nodes; const uint32_t dt = (uint32_t)out.dev_tris;
+        for (size_t i = 0; i < out.nodes.size(); ++i)
+            for (int k = 0; k < 4; ++k) { int32_t& c = out.nodes[i].children()[k]; c = i < host_blas_nodes ? rebase_ref(c, dn, dt) : (c >= 0 ? c + dn : c); }
+        if (out.closest_root >= 0) out.closest_root += dn;
+        if (out.shadow_root >= 0) out.shadow_root += dn;
+        for (std::vector<Instance>* list : {&cinst, &sinst})
+            for (Instance& in : *list) {
+                if (in.kind != NRAYS_SHAPE_TRIMESH) continue;
+                if (in.flags & kInstDeviceTmp) in.flags &= ~(uint32_t)kInstDeviceTmp; else in.blas_root = rebase_ref(in.blas_root, dn, dt);
+            }
+        if (out.tris.size() + out.dev_tris >= (1u << 28)) { err = "too many triangles"; return NRAYS_ERR_UNSUPPORTED; }
+    }
     out.instances.swap(cinst);
     out.shadow_instances.swap(sinst);
     for (const Instance& in : out.instances) out.links.push_back(InstLink{in.blas_root, in.flags});
     for (const Instance& in : out.shadow_instances) out.shadow_links.push_back(InstLink{in.blas_root, in.flags});
     // the traversal addresses a node as base + 32-bit byte offset (trace_device.h: load_planes)
-    if (out.nodes.size() >= ((size_t)1 << 25)) { err = "scene too large: more than 2^25 BVH nodes"; return NRAYS_ERR_BAD_ARG; }
+    if (out.nodes.size() + out.dev_nodes >= ((size_t)1 << 25)) { err = "scene too large: more than 2^25 BVH nodes"; return NRAYS_ERR_BAD_ARG; }
     return NRAYS_OK;
 }
 

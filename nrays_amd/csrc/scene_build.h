@@ -5,6 +5,7 @@
 #include <vector>
 
 #include "../../include/nrays_abi.h"
+#include "bvh_device.h"
 #include "device_types.h"
 
 namespace nrays {
@@ -15,6 +16,10 @@ struct HostTexture {
 };
 
 struct HostScene {
+    // BLASes built on the device (bvh_device.hip) occupy the FIRST dev_nodes / dev_tris entries of the scene's node / triangle arrays,
+    // in the order of dev_blas; the host-built arrays below follow them (their refs are shifted when the scene is complete).
+    std::vector<DeviceBlas> dev_blas;
+    size_t dev_nodes = 0, dev_tris = 0;
     std::vector<BvhNode> nodes;
     std::vector<TriRec> tris;
     std::vector<TriUv> triuvs;
@@ -49,5 +54,10 @@ struct HostScene {
 
 // Returns NRAYS_OK or a negative NraysStatus with `err` set.
 int build_host_scene(const NraysSceneDesc* desc, HostScene& out, std::string& err);
+
+// Test probe behind nrays_debug_blas_build: the BLAS of ONE mesh from the host builder or the device builder, copied to the host.
+// nodes: local indices (root = node 0 unless the BLAS is a single leaf), tri_ids: TriRec::tri_id per leaf slot.
+struct BlasProbe { std::vector<BvhNode> nodes; std::vector<uint32_t> tri_ids; int32_t root = kEmptyChild; int max_depth = 0; bool hairy = false; };
+int build_blas_probe(const NraysMesh* mesh, bool device, bool presplit_on, BlasProbe& out, std::string& err);
 
 } // namespace nrays

@@ -1,0 +1,155 @@
+"""The device BLAS builder (nrays_amd/csrc/bvh_device.hip) against the host builder (bvh_build.cpp / scene_build.cpp) — both stand for
+ncollide's BVT::new_balanced inside TriMesh::new (reference: examples/loader3d.rs:695, src/scene.rs:119-133).  Same split rule, same
+f32 arithmetic: from the same references the two must return the SAME 4-wide nodes (planes, child refs, depth-first order) and the
+same triangles behind every leaf; a scene whose BLASes were built on the device must render the frame of the host-built scene bit
+for bit (a BVT query's answer does not depend on the tree, D-2) with the same ray classes AND the same number of AABB tests."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import nrays_amd as nr
+from nrays_amd import abi
+from tools import scenes_util as su, standins
+
+pytestmark = pytest.mark.gpu
+
+
+def _mesh(pts, idx):
+    pts = np.ascontiguousarray(np.asarray(pts, np.float32).astype(np.float64))
+    idx = np.ascontiguousarray(np.asarray(idx, np.uint32))
+    m = abi.NraysMesh(len(pts), len(idx), pts.ctypes.data_as(C.POINTER(C.c_double)), None, idx.ctypes.data_as(C.POINTER(C.c_uint32)))
+    return m, (pts, idx)
+
+
+def _build(pts, idx, device, presplit=False):
+    m, keep = _mesh(pts, idx)
+    cap_r = 8 * len(idx) + 64
+    nodes = np.zeros((cap_r, 32), np.float32)
+    tri = np.zeros(cap_r, np.uint32)
+    d = abi.NraysBlasDump()
+    d.node_capacity = cap_r; d.ref_capacity = cap_r
+    d.nodes = nodes.ctypes.data_as(C.POINTER(C.c_float)); d.tri_ids = tri.ctypes.data_as(C.POINTER(C.c_uint32))
+    abi.check(abi.load_hip_lib().nrays_debug_blas_build(C.byref(m), (1 if device else 0) | (0 if presplit else 2), C.byref(d)))
+    return dict(nodes=nodes[:d.num_nodes].copy(), tri=tri[:d.num_refs].copy(), root=d.root, depth=d.max_depth, hairy=d.hairy)
+
+
+def _leaves(b):
+    """{(first, count): sorted triangle ids} over all leaf refs of the tree."""
+    refs = b["nodes"][:, 8:12].view(np.int32).ravel() if len(b["nodes"]) else np.asarray([b["root"]], np.int32)
+    out = {}
+    for r in refs:
+        if r < 0 and r != -2**31:
+            v = int(~r) & 0xffffffff
+            out[(v >> 3, (v & 7) + 1)] = tuple(sorted(b["tri"][(v >> 3):(v >> 3) + (v & 7) + 1].tolist()))
+    return out
+
+
+def _same_tree(h, d):
+    assert d["root"] == h["root"] and d["depth"] == h["depth"], (d["root"], h["root"], d["depth"], h["depth"])
+    assert d["nodes"].shape == h["nodes"].shape, (d["nodes"].shape, h["nodes"].shape)
+    if len(h["nodes"]):
+        hp, dp = np.delete(h["nodes"], np.s_[8:12], axis=1), np.delete(d["nodes"], np.s_[8:12], axis=1)
+        bad = np.nonzero((hp != dp).any(axis=1))[0]
+        assert bad.size == 0, ("first differing node", int(bad[0]), hp[bad[0]], dp[bad[0]])
+        hr, dr = h["nodes"][:, 8:12].view(np.int32), d["nodes"][:, 8:12].view(np.int32)
+        bad = np.nonzero((hr != dr).any(axis=1))[0]
+        assert bad.size == 0, ("first node with other child refs", int(bad[0]), hr[bad[0]], dr[bad[0]])
+    assert len(d["tri"]) == len(h["tri"])
+    assert _leaves(d) == _leaves(h)
+
+
+def _soup(n, seed, spread=1.0, size=0.05):
+    rng = np.random.default_rng(seed)
+    c = rng.uniform(-spread, spread, (n, 1, 3))
+    pts = (c + rng.uniform(-size, size, (n, 3, 3))).reshape(-1, 3)
+    return pts, np.arange(3 * n, dtype=np.uint32).reshape(n, 3)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 8, 9, 63, 256, 257, 300, 1000, 5000, 70000])
+def test_random_soups_give_the_host_tree(gpu, n):
+    pts, idx = _soup(n, 100 + n)
+    _same_tree(_build(pts, idx, False), _build(pts, idx, True))
+
+
+def test_clustered_and_flat_meshes_give_the_host_tree(gpu):
+    # clusters of very different sizes (uneven SAH splits), a flat sheet (one axis unusable), a line of triangles
+    rng = np.random.default_rng(7)
+    parts = [_soup(20000, 1, 0.01, 0.001)[0] + [5, 0, 0], _soup(3000, 2, 3.0, 0.2)[0], _soup(40000, 3, 0.5, 0.002)[0] - [0, 4, 0]]
+    pts = np.concatenate(parts); idx = np.arange(len(pts), dtype=np.uint32).reshape(-1, 3)
+    _same_tree(_build(pts, idx, False), _build(pts, idx, True))
+    sheet, si = _soup(6000, 4, 2.0, 0.03); sheet[:, 1] = 0.25
+    _same_tree(_build(sheet, si, False), _build(sheet, si, True))
+    line, li = _soup(900, 5, 2.0, 0.01); line[:, 1] = 0.0; line[:, 2] = 0.0
+    _same_tree(_build(line, li, False), _build(line, li, True))
+
+
+def test_coinciding_centroids_split_by_index(gpu):
+    """Copies of one triangle: every centroid coincides, the builders split by index (bvh_build.cpp: best_axis < 0).  Which copy lands in
+    which leaf depends on the order inside the range, so only the shape is compared: same leaf sizes in the same places."""
+    tri = np.asarray([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+    for n in (2, 9, 40, 700):
+        pts = np.tile(tri, (n, 1)); idx = np.arange(3 * n, dtype=np.uint32).reshape(n, 3)
+        h, d = _build(pts, idx, False), _build(pts, idx, True)
+        assert d["nodes"].shape == h["nodes"].shape and d["depth"] == h["depth"]
+        assert sorted(_leaves(d).keys()) == sorted(_leaves(h).keys())
+        assert sorted(d["tri"].tolist()) == sorted(h["tri"].tolist()) == list(range(n))
+        assert np.array_equal(np.delete(h["nodes"], np.s_[8:12], axis=1), np.delete(d["nodes"], np.s_[8:12], axis=1))
+
+
+def test_presplit_on_the_device_matches_the_host_rule(gpu):
+    """Hair (thin diagonal triangles): both builders classify it hair-like; the device splits against the threshold its budget amounts to
+    over ALL pieces (a histogram), the host against the one a sample gives — same rule, nearly the same references; every triangle must
+    still be reachable, and a mesh the rule leaves alone must come out exactly like the host's."""
+    pts, idx, _ = standins.hairball_geometry(strands=120, sides=6, segments=30)
+    h, d = _build(pts, idx, False, presplit=True), _build(pts, idx, True, presplit=True)
+    assert h["hairy"] == 1 and d["hairy"] == 1
+    assert len(d["tri"]) > 2 * len(idx) and 0.85 * len(h["tri"]) <= len(d["tri"]) <= 1.01 * len(h["tri"]), (len(d["tri"]), len(h["tri"]))
+    assert set(d["tri"].tolist()) == set(range(len(idx)))
+    assert abs(len(d["nodes"]) - len(h["nodes"])) <= 0.15 * len(h["nodes"])
+    pts, idx = _soup(4000, 9, 1.0, 0.2)  # fat random triangles: few qualify, the budget never binds -> the heap and the threshold rule agree
+    h, d = _build(pts, idx, False, presplit=True), _build(pts, idx, True, presplit=True)
+    assert h["hairy"] == 0 and d["hairy"] == 0 and len(d["tri"]) == len(h["tri"])
+    assert np.array_equal(np.delete(h["nodes"], np.s_[8:12], axis=1), np.delete(d["nodes"], np.s_[8:12], axis=1))
+
+
+def test_bad_meshes_are_refused_like_on_the_host(gpu):
+    pts, idx = _soup(100, 1)
+    bad = idx.copy(); bad[50, 1] = 10**6
+    m, keep = _mesh(pts, bad)
+    d = abi.NraysBlasDump()
+    lib = abi.load_hip_lib()
+    assert lib.nrays_debug_blas_build(C.byref(m), 1 | 2, C.byref(d)) == lib.nrays_debug_blas_build(C.byref(m), 2, C.byref(d)) != 0
+    p64 = np.asarray(pts, np.float32).astype(np.float64); p64[7, 2] += 1e-12  # not f32-exact
+    m = abi.NraysMesh(len(p64), len(idx), p64.ctypes.data_as(C.POINTER(C.c_double)), None, np.ascontiguousarray(idx).ctypes.data_as(C.POINTER(C.c_uint32)))
+    assert lib.nrays_debug_blas_build(C.byref(m), 1 | 2, C.byref(d)) == lib.nrays_debug_blas_build(C.byref(m), 2, C.byref(d)) != 0
+    assert b"f32" in lib.nrays_last_error()
+
+
+def _frame(make, w, h, **kw):
+    import torch
+    sc, cam = make()
+    p, _ = su.camera_params(cam, w, h, **kw)
+    dev = torch.empty((h, w, 3), dtype=torch.float32, device="cuda")
+    abi.check(abi.load_hip_lib().nrays_render_device_instrumented(sc.device_handle(), C.byref(p), C.c_void_p(dev.data_ptr()), None))
+    st = nr.get_stats(sc)
+    return dev.cpu().numpy(), st.as_dict()
+
+
+@pytest.mark.parametrize("scene,res,min_tris", [("hair", (240, 136), 1), ("sponza", (320, 180), 1), ("sponza", (320, 180), 3000)])
+def test_device_built_scenes_render_the_host_built_frame(gpu, monkeypatch, scene, res, min_tris):
+    """min_tris = 1: every BLAS on the device; 3000: the sponza stand-in's large BLASes on the device and its small ones on the host —
+    the mixed layout (device segments first, host refs shifted behind them)."""
+    make = (lambda: standins.hairball_scene(strands=300)) if scene == "hair" else (lambda: standins.sponza_scene())
+    monkeypatch.setenv("NRAYS_GPU_BUILD", "0")
+    want, wst = _frame(make, *res)
+    monkeypatch.delenv("NRAYS_GPU_BUILD")
+    monkeypatch.setenv("NRAYS_GPU_BUILD_MIN", str(min_tris))
+    got, gst = _frame(make, *res)
+    assert np.array_equal(got, want), np.abs(got - want).max()
+    for k in ("rays_primary", "rays_reflection", "rays_refraction", "rays_shadow", "hit_records"):
+        assert gst[k] == wst[k], (k, gst[k], wst[k])
+    if scene == "sponza":  # no hair: pre-splitting is mild and never budget-bound -> the very same trees, the very same visits
+        assert gst["node_tests"] == wst["node_tests"] and gst["tri_tests"] == wst["tri_tests"], (gst, wst)
+    else:
+        assert abs(gst["node_tests"] - wst["node_tests"]) <= 0.05 * wst["node_tests"], (gst["node_tests"], wst["node_tests"])

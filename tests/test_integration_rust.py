@@ -33,7 +33,7 @@ def _rust_structs():
 
 def test_repr_c_structs_match_the_header_field_for_field():
     c, r = _c_structs(), _rust_structs()
-    assert set(c) == {"NraysLight", "NraysTexture", "NraysMaterial", "NraysMesh", "NraysNode", "NraysSceneDesc", "NraysRenderParams", "NraysStats", "NraysCastResult", "NraysTileCosts", "NraysMultiTimings"}
+    assert set(c) == {"NraysLight", "NraysTexture", "NraysMaterial", "NraysMesh", "NraysNode", "NraysSceneDesc", "NraysRenderParams", "NraysStats", "NraysCastResult", "NraysTileCosts", "NraysMultiTimings", "NraysBlasDump"}
     for name, fields in c.items():
         assert r.get(name) == fields, (name, fields, r.get(name))
         assert re.search(r"#\[repr\(C\)\]\s*(#\[derive[^\]]*\]\s*)?pub struct %s " % name, FFI), name
