@@ -101,8 +101,29 @@ __device__ inline int bin_of(float cent, float lo, float scale) {
     return min(max(b, 0), kSahBins - 1);
 }
 
+// ---- scans inside the two 32-lane halves of a wave with DPP (no LDS traffic: the wave's LDS port is busy with the bins) -----------
+// row_shr:1,2,4,8 scan a row of 16 lanes, row_bcast:15 on rows 1 and 3 adds the total of the row below: lane 31 / lane 63 end up with
+// the totals of lanes 0..31 / 32..63.  A lane whose source lies outside its row keeps `identity`.
+template <int CTRL, int ROW_MASK> __device__ inline int dpp_i(int identity, int x) { return __builtin_amdgcn_update_dpp(identity, x, CTRL, ROW_MASK, 0xf, false); }
+template <int CTRL, int ROW_MASK> __device__ inline float dpp_f(float identity, float x) { return __int_as_float(dpp_i<CTRL, ROW_MASK>(__float_as_int(identity), __float_as_int(x))); }
+#define NR_SCAN32(x, identity, OP, DPP)                     \
+    do {                                                    \
+        x = OP(x, DPP<0x111, 0xf>(identity, x));            \
+        x = OP(x, DPP<0x112, 0xf>(identity, x));            \
+        x = OP(x, DPP<0x114, 0xf>(identity, x));            \
+        x = OP(x, DPP<0x118, 0xf>(identity, x));            \
+        x = OP(x, DPP<0x142, 0xa>(identity, x));            \
+    } while (0)
+__device__ inline int add_i(int a, int b) { return a + b; }
+__device__ inline float scan32_min(float x) { NR_SCAN32(x, INF_F, fminf, dpp_f); return x; }
+__device__ inline float scan32_max(float x) { NR_SCAN32(x, -INF_F, fmaxf, dpp_f); return x; }
+__device__ inline uint32_t scan32_add(uint32_t v) { int x = (int)v; NR_SCAN32(x, 0, add_i, dpp_i); return (uint32_t)x; }
+__device__ inline float lane_f(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+__device__ inline uint32_t lane_u(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
+
 // ---- the split rule of Builder::build for one node, evaluated by one wave ---------------------------------------------
 // bins: mn / mx = kBinWords encoded words each, cnt = 96 counts ([axis][bin]); every argument and every result is wave-uniform.
+// (An axis whose centroids coincide has no entries in its bins: its candidates have a zero count on one side and never compete.)
 struct SplitResult {
     int axis, split; // axis < 0: every centroid coincides (split by index)
     bool leaf;
@@ -112,33 +133,35 @@ struct SplitResult {
 __device__ void select_split(const uint32_t* mn, const uint32_t* mx, const uint32_t* cnt, const Task& t, int max_leaf, float prim_cost, SplitResult& r) {
     const int lane = lane_id(), half = lane >> 5, j = lane & 31;
     const int bin = half ? 31 - j : j; // lower half: prefix over bins 0..j; upper half: suffix over bins 31-j..31
-    float best_cost = INF_F; int best_key = -1;
-    for (int axis = 0; axis < 3; ++axis) {
-        if (!(t.cmx[axis] > t.cmn[axis])) continue;
+    float area[3]; uint32_t c[3];
+    for (int axis = 0; axis < 3; ++axis) { // the three axes side by side: one LDS round trip, then VALU only
         const int idx = axis * 32 + bin;
         float bmn[3], bmx[3];
-        for (int a = 0; a < 3; ++a) { bmn[a] = dec_min(mn[idx * 6 + a]); bmx[a] = dec_max(mx[idx * 6 + a]); }
-        uint32_t c = cnt[idx];
-        for (int off = 1; off < 32; off <<= 1) {
-            float on[3], ox[3];
-            for (int a = 0; a < 3; ++a) { on[a] = __shfl_up(bmn[a], off, 32); ox[a] = __shfl_up(bmx[a], off, 32); }
-            uint32_t oc = (uint32_t)__shfl_up((int)c, off, 32);
-            if (j >= off) { for (int a = 0; a < 3; ++a) { bmn[a] = fminf(bmn[a], on[a]); bmx[a] = fmaxf(bmx[a], ox[a]); } c += oc; }
-        }
-        const float area = half_area3(bmn, bmx);
-        const int src = lane <= 30 ? 62 - lane : lane; // the suffix over bins lane+1..31 sits in lane 32 + (31 - (lane + 1))
-        const float rarea = __shfl(area, src, 64);
-        const uint32_t rc = (uint32_t)__shfl((int)c, src, 64);
-        if (lane <= 30 && c > 0u && rc > 0u) {
-            const float cost = area * (float)c + rarea * (float)rc;
+        for (int a = 0; a < 3; ++a) { bmn[a] = scan32_min(dec_min(mn[idx * 6 + a])); bmx[a] = scan32_max(dec_max(mx[idx * 6 + a])); }
+        c[axis] = scan32_add(cnt[idx]);
+        area[axis] = half_area3(bmn, bmx);
+    }
+    float best_cost = INF_F; int best_key = -1;
+    const int src = lane <= 30 ? 62 - lane : lane; // the suffix over bins lane+1..31 sits in lane 32 + (31 - (lane + 1))
+    for (int axis = 0; axis < 3; ++axis) {
+        const float rarea = __shfl(area[axis], src, 64);
+        const uint32_t rc = (uint32_t)__shfl((int)c[axis], src, 64);
+        if (lane <= 30 && c[axis] > 0u && rc > 0u) {
+            const float cost = area[axis] * (float)c[axis] + rarea * (float)rc;
             if (cost < best_cost) { best_cost = cost; best_key = axis * 32 + lane; }
         }
     }
-    for (int off = 32; off >= 1; off >>= 1) { // first minimum in (axis, bin) order, like the sequential sweep
-        const float oc = __shfl_xor(best_cost, off, 64);
-        const int ok = __shfl_xor(best_key, off, 64);
-        if (ok >= 0 && (best_key < 0 || oc < best_cost || (oc == best_cost && ok < best_key))) { best_cost = oc; best_key = ok; }
-    }
+    if (lane > 30) { best_cost = INF_F; best_key = -1; }
+    // first minimum in (axis, bin) order, like the sequential sweep: a scan over the lower half, lane 31 holds the winner
+#define NR_ARGMIN_STEP(CTRL, ROW_MASK)                                                                                            \
+    do {                                                                                                                          \
+        const float oc = dpp_f<CTRL, ROW_MASK>(INF_F, best_cost);                                                                 \
+        const int ok = dpp_i<CTRL, ROW_MASK>(-1, best_key);                                                                       \
+        if (ok >= 0 && (best_key < 0 || oc < best_cost || (oc == best_cost && ok < best_key))) { best_cost = oc; best_key = ok; } \
+    } while (0)
+    NR_ARGMIN_STEP(0x111, 0xf); NR_ARGMIN_STEP(0x112, 0xf); NR_ARGMIN_STEP(0x114, 0xf); NR_ARGMIN_STEP(0x118, 0xf); NR_ARGMIN_STEP(0x142, 0xa);
+#undef NR_ARGMIN_STEP
+    best_cost = lane_f(best_cost, 31); best_key = __builtin_amdgcn_readlane(best_key, 31);
     r.leaf = false;
     if ((int)t.count <= max_leaf) { // SAH: an exact f64 ray / triangle test costs about prim_cost times a node visit
         const float ha = half_area3(t.bmn, t.bmx);
@@ -154,23 +177,21 @@ __device__ void select_split(const uint32_t* mn, const uint32_t* mx, const uint3
     const int idx = r.axis * 32 + j;
     const bool mine = half == 0 ? j <= r.split : j > r.split;
     float v[12]; // box min, centroid min, box max, centroid max
-    for (int a = 0; a < 6; ++a) { v[a] = mine ? dec_min(mn[idx * 6 + a]) : INF_F; v[6 + a] = mine ? dec_max(mx[idx * 6 + a]) : -INF_F; }
-    uint32_t c = mine ? cnt[idx] : 0u;
-    for (int off = 16; off >= 1; off >>= 1) {
-        for (int a = 0; a < 6; ++a) { v[a] = fminf(v[a], __shfl_xor(v[a], off, 64)); v[6 + a] = fmaxf(v[6 + a], __shfl_xor(v[6 + a], off, 64)); }
-        c += (uint32_t)__shfl_xor((int)c, off, 64);
-    }
+    for (int a = 0; a < 6; ++a) { v[a] = scan32_min(mine ? dec_min(mn[idx * 6 + a]) : INF_F); v[6 + a] = scan32_max(mine ? dec_max(mx[idx * 6 + a]) : -INF_F); }
+    const uint32_t cc = scan32_add(mine ? cnt[idx] : 0u);
     for (int a = 0; a < 3; ++a) {
-        r.lb_mn[a] = bcast_f(v[a], 0); r.lc_mn[a] = bcast_f(v[3 + a], 0); r.lb_mx[a] = bcast_f(v[6 + a], 0); r.lc_mx[a] = bcast_f(v[9 + a], 0);
-        r.rb_mn[a] = bcast_f(v[a], 32); r.rc_mn[a] = bcast_f(v[3 + a], 32); r.rb_mx[a] = bcast_f(v[6 + a], 32); r.rc_mx[a] = bcast_f(v[9 + a], 32);
+        r.lb_mn[a] = lane_f(v[a], 31); r.lc_mn[a] = lane_f(v[3 + a], 31); r.lb_mx[a] = lane_f(v[6 + a], 31); r.lc_mx[a] = lane_f(v[9 + a], 31);
+        r.rb_mn[a] = lane_f(v[a], 63); r.rc_mn[a] = lane_f(v[3 + a], 63); r.rb_mx[a] = lane_f(v[6 + a], 63); r.rc_mx[a] = lane_f(v[9 + a], 63);
     }
-    r.nleft = bcast_u(c, 0);
+    r.nleft = lane_u(cc, 31);
 }
 
 // Twelve-value wave reduction (min of v[0..5], max of v[6..11]); the result is uniform.
 __device__ inline void wave_reduce12(float v[12]) {
-    for (int off = 32; off >= 1; off >>= 1)
-        for (int a = 0; a < 6; ++a) { v[a] = fminf(v[a], __shfl_xor(v[a], off, 64)); v[6 + a] = fmaxf(v[6 + a], __shfl_xor(v[6 + a], off, 64)); }
+    for (int a = 0; a < 6; ++a) {
+        const float lo = scan32_min(v[a]), hi = scan32_max(v[6 + a]);
+        v[a] = fminf(lane_f(lo, 31), lane_f(lo, 63)); v[6 + a] = fmaxf(lane_f(hi, 31), lane_f(hi, 63));
+    }
 }
 __device__ inline void acc12(float v[12], const float mn[3], const float mx[3]) {
     for (int a = 0; a < 3; ++a) {
@@ -763,6 +784,7 @@ int build_impl(const std::vector<DeviceMeshPart>& parts, const DeviceBuildOption
     for (auto& kv : uploads) {
         kv.second.second = a1.take<char>(kv.second.first);
         DB_TRY(hipMemcpy(kv.second.second, kv.first, kv.second.first, hipMemcpyHostToDevice));
+        if (verbose) { char what[64]; snprintf(what, sizeof what, "  upload of %.1f MB", kv.second.first / 1048576.0); sw.lap(what); }
     }
     TriRec* recs = a1.take<TriRec>(n); TriUv* uvs = a1.take<TriUv>(n); float* tbox = a1.take<float>(6 * n);
     double* part_area = a1.take<double>(nblocks_tri); double* part_tri2 = a1.take<double>(nblocks_tri);
