@@ -167,10 +167,10 @@ struct Blas {
 #define NR_PRIM_COST_HAIRY 0.7f // re-tuned with the quorum-ended node phases of round 3 (0.35 before): hairball 2.36 -> 2.27 ms, 14.6 -> 9.0 triangle tests per ray
 #endif
 #ifndef NR_PRESPLIT_BUDGET_HAIRY
-#define NR_PRESPLIT_BUDGET_HAIRY 5.0 // re-tuned with the cheaper node step of round 2 (3.0 before): hairball 3.06 -> 2.97 ms, 15.1 -> 11.2 triangle tests per ray; 8.0 gives 2.93 ms for twice the references
+#define NR_PRESPLIT_BUDGET_HAIRY 8.0 // round 4 (builds on the device cost milliseconds): 5.0 -> 8.0 with the finer rule below
 #endif
 #ifndef NR_PRESPLIT_MINGAIN_HAIRY
-#define NR_PRESPLIT_MINGAIN_HAIRY 0.05
+#define NR_PRESPLIT_MINGAIN_HAIRY 0.02 // round 4, tools/build_sweep.py (profiles/r04_build_sweep.log): 0.05 -> 0.02: hairball 2.04 -> 1.95 ms (9.0 -> 6.1 triangle tests per ray, 1.5 -> 2.3 GB); below it the frame stays at 1.95 (the node loop, not the triangle tests, bounds it)
 #endif
 // The exact procedure: pieces split in order of decreasing empty area until the budget is used up.  `tris` lists the
 // triangles taking part (all of them, or a sample); boxes[k] / owner[k] describe reference k (k < tris.size(): the
@@ -291,6 +291,13 @@ static DeviceBuildOptions device_options(bool presplit_on) {
     o.max_leaf = NR_MAX_LEAF; o.prim_cost = NR_PRIM_COST; o.prim_cost_hairy = NR_PRIM_COST_HAIRY;
     o.budget = NR_PRESPLIT_BUDGET; o.budget_hairy = NR_PRESPLIT_BUDGET_HAIRY; o.min_gain = NR_PRESPLIT_MINGAIN; o.min_gain_hairy = NR_PRESPLIT_MINGAIN_HAIRY;
     o.hairy_emptiness = NR_PRESPLIT_HAIRY; o.presplit = presplit_on;
+    // tuning overrides, read per scene (tools/build_sweep.py): a device build costs milliseconds, so the quality knobs can be swept in one process
+    auto envd = [](const char* name, double& v) { if (const char* e = getenv(name)) v = atof(e); };
+    auto envf = [](const char* name, float& v) { if (const char* e = getenv(name)) v = (float)atof(e); };
+    envd("NRAYS_PRESPLIT_BUDGET", o.budget); envd("NRAYS_PRESPLIT_BUDGET_HAIRY", o.budget_hairy);
+    envd("NRAYS_PRESPLIT_MINGAIN", o.min_gain); envd("NRAYS_PRESPLIT_MINGAIN_HAIRY", o.min_gain_hairy);
+    envf("NRAYS_PRIM_COST", o.prim_cost); envf("NRAYS_PRIM_COST_HAIRY", o.prim_cost_hairy);
+    if (const char* e = getenv("NRAYS_MAX_LEAF")) o.max_leaf = atoi(e);
     return o;
 }
 

@@ -24,7 +24,7 @@ def _mesh(pts, idx):
 
 def _build(pts, idx, device, presplit=False):
     m, keep = _mesh(pts, idx)
-    cap_r = 8 * len(idx) + 64
+    cap_r = 12 * len(idx) + 64
     nodes = np.zeros((cap_r, 32), np.float32)
     tri = np.zeros(cap_r, np.uint32)
     d = abi.NraysBlasDump()
