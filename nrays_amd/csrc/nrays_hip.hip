@@ -15,6 +15,9 @@
 //   k_resolve   divides by ray_per_pixel when it is > 1 (scene.rs:94).
 //   k_untile    un-permutes gathered multi-GPU tile buffers.
 #include <hip/hip_runtime.h>
+#ifndef NR_TILE_PRIO
+#define NR_TILE_PRIO 0 // k < NR_TILE_PRIO: priority 3, < 3x: 2, < 8x: 1 (0 = off)
+#endif
 
 #include <algorithm>
 #include <chrono>
@@ -323,6 +326,11 @@ __global__ void __launch_bounds__(kBlock, OCC ? NR_OCC3_AS : waves_per_simd(FEAT
           }
           if (ordered) { first = R.tile_order[k * 8u + victim]; last = first + 1u; }
           else { first = victim * per + k; last = k + grab < len ? first + grab : victim * per + len; }
+#if NR_TILE_PRIO
+          // cost-ordered lists: the earlier an entry sits in its list the longer its tile — the frame cannot end before the longest chains do,
+          // so their waves issue ahead of the SIMD's other wave (s_setprio only orders the waves of one SIMD; results do not depend on it)
+          if (ordered) { if (k < NR_TILE_PRIO) __builtin_amdgcn_s_setprio(3); else if (k < 3u * NR_TILE_PRIO) __builtin_amdgcn_s_setprio(2); else if (k < 8u * NR_TILE_PRIO) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+#endif
           if (static_first) { static_first = false; victim = xcc_id(); } // from here on: this XCD's counter
           if (prefetch) pending = issue_grab(work_counters, victim, grab); // issued now, consumed after the tiles below
       }
