@@ -87,6 +87,7 @@ __device__ inline float half_area3(const float mn[3], const float mx[3]) { // bv
 #define PHASE_END(ctr) do {} while (0)
 #endif
 __device__ inline void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+__device__ inline float sel3(const float v[3], int a) { return a == 0 ? v[0] : (a == 1 ? v[1] : v[2]); } // (a private array indexed at run time would be placed in scratch or LDS)
 __device__ inline int lane_id() { return (int)(threadIdx.x & 63u); }
 __device__ inline float bcast_f(float v, int src) { return __shfl(v, src, 64); }
 __device__ inline uint32_t bcast_u(uint32_t v, int src) { return (uint32_t)__shfl((int)v, src, 64); }
@@ -286,12 +287,22 @@ __global__ __launch_bounds__(256) void k_presplit(const TriRec* recs, const floa
                 }
                 if (sp == 0) break;
                 --sp;
-                cur = stack[sp].poly; box = stack[sp].box; slot = stack[sp].slot; depth = stack[sp].depth;
+                const SplitFrame& f = stack[sp]; // only the vertices in use travel (a frame is 328 bytes, a piece has 3 - 5 vertices)
+                cur.n = f.poly.n;
+                for (int k = 0; k < cur.n; ++k) for (int d = 0; d < 3; ++d) cur.v[k][d] = f.poly.v[k][d];
+                box = f.box; slot = f.slot; depth = f.depth;
                 continue;
             }
             if (MODE == kModeHist) atomicAdd(&hist[__float_as_uint((float)gain) >> kHistShift], 1u);
-            stack[sp].poly = hi; stack[sp].box = bh; stack[sp].slot = next++; stack[sp].depth = depth + 1; ++sp;
-            cur = lo; box = bl; ++depth;
+            {
+                SplitFrame& f = stack[sp];
+                f.poly.n = hi.n;
+                for (int k = 0; k < hi.n; ++k) for (int d = 0; d < 3; ++d) f.poly.v[k][d] = hi.v[k][d];
+                f.box = bh; f.slot = next++; f.depth = depth + 1; ++sp;
+            }
+            cur.n = lo.n;
+            for (int k = 0; k < lo.n; ++k) for (int d = 0; d < 3; ++d) cur.v[k][d] = lo.v[k][d];
+            box = bl; ++depth;
         }
         if (MODE != kModeEmit) counts[t] = (uint32_t)next;
     }
@@ -409,7 +420,7 @@ __global__ __launch_bounds__(256) void k_select(const Task* tasks, uint32_t nt, 
             L[a] = r.lb_mn[a]; L[3 + a] = r.lc_mn[a]; L[6 + a] = r.lb_mx[a]; L[9 + a] = r.lc_mx[a];
             R[a] = r.rb_mn[a]; R[3 + a] = r.rc_mn[a]; R[6 + a] = r.rb_mx[a]; R[9 + a] = r.rc_mx[a];
         }
-        si.axis = r.axis; si.split = r.split; si.mid = mid; si.lo = tk.cmn[r.axis]; si.scale = (float)kSahBins / (tk.cmx[r.axis] - tk.cmn[r.axis]);
+        si.axis = r.axis; si.split = r.split; si.mid = mid; si.lo = sel3(tk.cmn, r.axis); si.scale = (float)kSahBins / (sel3(tk.cmx, r.axis) - sel3(tk.cmn, r.axis));
         child_buf ^= kTaskBuf;
     }
     if (lane != 0) return;
@@ -429,25 +440,26 @@ __global__ __launch_bounds__(256) void k_select(const Task* tasks, uint32_t nt, 
     }
 }
 
+// lefts[c] = references of chunk c that go left (from the chunk's own bin counts: no pass over the references).
+__global__ __launch_bounds__(256) void k_chunk_lefts(const uint32_t* chunk_task, const uint32_t* chunk_cnt, const SplitInfo* split, uint32_t nchunks, uint32_t* lefts) {
+    const uint32_t c = blockIdx.x * 256u + threadIdx.x;
+    if (c >= nchunks) return;
+    const SplitInfo si = split[chunk_task[c]];
+    uint32_t s = 0;
+    if (si.axis >= 0) for (int b = 0; b <= si.split; ++b) s += chunk_cnt[(size_t)c * 96u + (uint32_t)(si.axis * 32 + b)];
+    lefts[c] = s;
+}
 // chunk_off[c] = references of chunk c's task that go left and sit in earlier chunks of that task; one workgroup.
-__global__ __launch_bounds__(1024) void k_part_scan(const uint32_t* chunk_task, const uint32_t* chunk_base, const uint32_t* chunk_cnt, const SplitInfo* split, uint32_t nchunks,
-                                                    uint32_t* chunk_off, uint32_t* scratch) {
+__global__ __launch_bounds__(1024) void k_part_scan(const uint32_t* chunk_task, const uint32_t* chunk_base, const uint32_t* lefts, uint32_t nchunks, uint32_t* chunk_off, uint32_t* scratch) {
     __shared__ uint32_t s_sum[1024];
     const uint32_t per = (nchunks + 1023u) / 1024u, lo = threadIdx.x * per, hi = min(nchunks, lo + per);
-    auto lefts = [&](uint32_t c) -> uint32_t {
-        const SplitInfo si = split[chunk_task[c]];
-        if (si.axis < 0) return 0u;
-        uint32_t s = 0;
-        for (int b = 0; b <= si.split; ++b) s += chunk_cnt[(size_t)c * 96u + (uint32_t)(si.axis * 32 + b)];
-        return s;
-    };
     uint32_t sum = 0;
-    for (uint32_t c = lo; c < hi; ++c) sum += lefts(c);
+    for (uint32_t c = lo; c < hi; ++c) sum += lefts[c];
     s_sum[threadIdx.x] = sum;
     __syncthreads();
     for (uint32_t off = 1; off < 1024u; off <<= 1) { uint32_t v = threadIdx.x >= off ? s_sum[threadIdx.x - off] : 0u; __syncthreads(); s_sum[threadIdx.x] += v; __syncthreads(); }
     uint32_t run = s_sum[threadIdx.x] - sum;
-    for (uint32_t c = lo; c < hi; ++c) { scratch[c] = run; run += lefts(c); }
+    for (uint32_t c = lo; c < hi; ++c) { scratch[c] = run; run += lefts[c]; }
     __threadfence_block();
     __syncthreads();
     for (uint32_t c = lo; c < hi; ++c) chunk_off[c] = scratch[c] - scratch[chunk_base[chunk_task[c]]];
@@ -497,15 +509,16 @@ __global__ __launch_bounds__(256) void k_small(const Task* small, uint32_t ns, c
                                                Node2* node2, Counters* ctr, int max_leaf, float prim_cost) {
     __shared__ uint32_t s_gid[4][kSmall];
     __shared__ float s_box[4][6][kSmall];
-    __shared__ uint16_t s_perm[4][kSmall], s_perm2[4][kSmall];
+    __shared__ uint8_t s_perm[4][kSmall], s_perm2[4][kSmall]; // positions inside the node's <= 256 references
+    static_assert(kSmall <= 256, "a reference's slot must fit a byte");
     __shared__ uint32_t s_mn[4][kBinWords], s_mx[4][kBinWords], s_cnt[4][96];
-    __shared__ Task s_stack[4][12];
+    __shared__ Task s_stack[4][9]; // the larger child waits: depth <= log2(kSmall)
     const uint32_t w = threadIdx.x >> 6;
     const uint32_t ti = blockIdx.x * 4u + w;
     if (ti >= ns) return;
     const int lane = lane_id();
     const unsigned long long lt = (1ull << lane) - 1ull;
-    uint32_t* gid = s_gid[w]; uint16_t* perm = s_perm[w]; uint16_t* perm2 = s_perm2[w];
+    uint32_t* gid = s_gid[w]; uint8_t* perm = s_perm[w]; uint8_t* perm2 = s_perm2[w];
     uint32_t* bmn = s_mn[w]; uint32_t* bmx = s_mx[w]; uint32_t* bcnt = s_cnt[w];
     Task cur = small[ti];
     const uint32_t gfirst = cur.first;
@@ -514,7 +527,7 @@ __global__ __launch_bounds__(256) void k_small(const Task* small, uint32_t ns, c
         const uint32_t* order = (cur.flags & kTaskBuf) ? order1 : order0;
         for (uint32_t i = (uint32_t)lane; i < cur.count; i += 64u) {
             const uint32_t id = order[gfirst + i];
-            gid[i] = id; perm[i] = (uint16_t)i;
+            gid[i] = id; perm[i] = (uint8_t)i;
             float mn[3], mx[3]; load_box(ref_box, id, mn, mx);
             for (int a = 0; a < 3; ++a) { s_box[w][a][i] = mn[a]; s_box[w][3 + a][i] = mx[a]; }
         }
@@ -527,6 +540,43 @@ __global__ __launch_bounds__(256) void k_small(const Task* small, uint32_t ns, c
         bool done = false;
         if (cur.count == 1u) {
             if (lane == 0) { order_final[gfirst + cur.first] = gid[perm[cur.first]]; set_ref(node2, ctr, cur.parent, cur.flags, make_leaf_ref(gfirst + cur.first, 1u)); }
+            done = true;
+        } else if (cur.count == 2u) {
+            // Two references, decided without bins — the same decision select_split() takes: on every axis whose centroids differ the two
+            // fall into bins 0 and 31, every candidate plane between them costs area(a) + area(b), and the first one in (axis, bin) order
+            // wins: the first such axis, left = the reference with the smaller centroid there.  No such axis: the two coincide -> a leaf
+            // (count <= max_leaf and no split to compare with), as the sequential builder decides.
+            const uint32_t e0 = perm[cur.first], e1 = perm[cur.first + 1u];
+            float m0[3], x0[3], m1[3], x1[3], c0[3], c1[3];
+            for (int a = 0; a < 3; ++a) { m0[a] = s_box[w][a][e0]; x0[a] = s_box[w][3 + a][e0]; m1[a] = s_box[w][a][e1]; x1[a] = s_box[w][3 + a][e1];
+                                          c0[a] = 0.5f * m0[a] + 0.5f * x0[a]; c1[a] = 0.5f * m1[a] + 0.5f * x1[a]; }
+            int axis = -1;
+            for (int a = 2; a >= 0; --a) if (cur.cmx[a] > cur.cmn[a]) axis = a;
+            bool leaf = axis < 0 && 2 <= max_leaf;
+            const float ha = half_area3(cur.bmn, cur.bmx);
+            if (axis >= 0 && 2 <= max_leaf) {
+                const float best_cost = half_area3(m0, x0) * 1.0f + half_area3(m1, x1) * 1.0f; // area * (float)1 + area * (float)1: the order of the operands does not matter
+                const float leaf_cost = ha * 2.0f * prim_cost, split_cost = best_cost * prim_cost + ha * 1.0f;
+                if (!(split_cost < leaf_cost)) leaf = true;
+            }
+            if (leaf) {
+                if (lane < 2) order_final[gfirst + cur.first + (uint32_t)lane] = gid[lane ? e1 : e0];
+                if (lane == 0) set_ref(node2, ctr, cur.parent, cur.flags, make_leaf_ref(gfirst + cur.first, 2u));
+            } else {
+                // (axis < 0 with max_leaf < 2: split by index — the order stays)
+                const bool swap = axis >= 0 && sel3(c1, axis) < sel3(c0, axis); // the reference in bin 0 goes left; stable otherwise
+                const uint32_t l = swap ? e1 : e0, r = swap ? e0 : e1;
+                const int32_t me = (int32_t)(gfirst + cur.first);
+                if (lane == 0) {
+                    Node2 n;
+                    for (int a = 0; a < 3; ++a) { n.lmin[a] = swap ? m1[a] : m0[a]; n.lmax[a] = swap ? x1[a] : x0[a]; n.rmin[a] = swap ? m0[a] : m1[a]; n.rmax[a] = swap ? x0[a] : x1[a]; }
+                    n.left = make_leaf_ref(gfirst + cur.first, 1u); n.right = make_leaf_ref(gfirst + cur.first + 1u, 1u);
+                    node2[me] = n;
+                    set_ref(node2, ctr, cur.parent, cur.flags, me);
+                    order_final[gfirst + cur.first] = gid[l]; order_final[gfirst + cur.first + 1u] = gid[r];
+                }
+                ++splits;
+            }
             done = true;
         } else {
             for (uint32_t i = (uint32_t)lane; i < (uint32_t)kBinWords; i += 64u) { bmn[i] = 0xffffffffu; bmx[i] = 0u; }
@@ -578,7 +628,7 @@ __global__ __launch_bounds__(256) void k_small(const Task* small, uint32_t ns, c
                     }
                     // stable partition of perm[first, first + count) by bin <= split
                     uint32_t l = 0, rr = 0;
-                    const float plo = cur.cmn[r.axis], pscale = (float)kSahBins / (cur.cmx[r.axis] - cur.cmn[r.axis]);
+                    const float plo = sel3(cur.cmn, r.axis), pscale = (float)kSahBins / (sel3(cur.cmx, r.axis) - sel3(cur.cmn, r.axis));
                     for (uint32_t base = 0; base < cur.count; base += 64u) {
                         const uint32_t i = base + (uint32_t)lane;
                         const bool valid = i < cur.count;
@@ -590,8 +640,8 @@ __global__ __launch_bounds__(256) void k_small(const Task* small, uint32_t ns, c
                         }
                         const unsigned long long ml = __ballot(valid && left), mr = __ballot(valid && !left);
                         if (valid) {
-                            if (left) perm2[cur.first + l + (uint32_t)__popcll(ml & lt)] = (uint16_t)e;
-                            else perm2[mid + rr + (uint32_t)__popcll(mr & lt)] = (uint16_t)e;
+                            if (left) perm2[cur.first + l + (uint32_t)__popcll(ml & lt)] = (uint8_t)e;
+                            else perm2[mid + rr + (uint32_t)__popcll(mr & lt)] = (uint8_t)e;
                         }
                         l += (uint32_t)__popcll(ml); rr += (uint32_t)__popcll(mr);
                     }
@@ -777,8 +827,10 @@ int build_impl(const std::vector<DeviceMeshPart>& parts, const DeviceBuildOption
     }
     size_t bytes1 = 0;
     for (auto& kv : uploads) bytes1 += padded<char>(kv.second.first);
+    size_t cub_bytes = 0; // what the prefix sum over the per-triangle reference counts needs
+    DB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, cub_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)(n + 1)));
     bytes1 += padded<TriRec>(n) + padded<TriUv>(n) + padded<float>(6 * n) + 2 * padded<double>(nblocks_tri) + padded<Counters>(1) + 2 * padded<uint32_t>(n + 1) +
-              padded<uint32_t>(kHistBins) + padded<SplitFrame>((size_t)split_grid * 256u * (kSplitDepthMax + 1)) + (1u << 20);
+              padded<uint32_t>(kHistBins) + padded<SplitFrame>((size_t)split_grid * 256u * (kSplitDepthMax + 1)) + padded<char>(cub_bytes) + 4096;
     DB_TRY(a1.reserve(bytes1));
     sw.lap("allocation (phase 1)");
     for (auto& kv : uploads) {
@@ -791,7 +843,7 @@ int build_impl(const std::vector<DeviceMeshPart>& parts, const DeviceBuildOption
     Counters* ctr = a1.take<Counters>(1);
     uint32_t* counts = a1.take<uint32_t>(n + 1); uint32_t* offsets = a1.take<uint32_t>(n + 1); uint32_t* hist = a1.take<uint32_t>(kHistBins);
     SplitFrame* frames = a1.take<SplitFrame>((size_t)split_grid * 256u * (kSplitDepthMax + 1));
-    void* cub_tmp1 = a1.take<char>(1u << 19);
+    void* cub_tmp1 = a1.take<char>(cub_bytes + 16);
     if (!frames || !cub_tmp1) { err = "device BLAS build: arena overflow (phase 1)"; return NRAYS_ERR_OOM; }
     sw.lap("upload of the mesh arrays");
     Counters h_ctr; std::memset(&h_ctr, 0, sizeof h_ctr);
@@ -831,7 +883,7 @@ int build_impl(const std::vector<DeviceMeshPart>& parts, const DeviceBuildOption
         const size_t budget = (size_t)((hairy ? opt.budget_hairy : opt.budget) * (double)n);
         DB_TRY(hipMemset(hist, 0, kHistBins * sizeof(uint32_t)));
         hipLaunchKernelGGL(k_presplit<kModeHist>, dim3(split_grid), dim3(256), 0, 0, recs, tbox, (uint32_t)n, min_gain, frames, counts, offsets, hist, (float*)nullptr, (uint32_t*)nullptr);
-        size_t tmp_bytes = 1u << 19;
+        size_t tmp_bytes = cub_bytes;
         DB_TRY(hipcub::DeviceScan::ExclusiveSum(cub_tmp1, tmp_bytes, counts, offsets, (int)(n + 1)));
         uint32_t extra = 0;
         DB_TRY(hipMemcpy(&extra, offsets + n, 4, hipMemcpyDeviceToHost));
@@ -845,7 +897,7 @@ int build_impl(const std::vector<DeviceMeshPart>& parts, const DeviceBuildOption
             thr = std::max(min_gain, (double)edge);
             // (float)gain rounds to nearest: a piece just below the edge may have been filed above it; `gain > thr` is what both passes below apply
             hipLaunchKernelGGL(k_presplit<kModeCount>, dim3(split_grid), dim3(256), 0, 0, recs, tbox, (uint32_t)n, thr, frames, counts, offsets, hist, (float*)nullptr, (uint32_t*)nullptr);
-            tmp_bytes = 1u << 19;
+            tmp_bytes = cub_bytes;
             DB_TRY(hipcub::DeviceScan::ExclusiveSum(cub_tmp1, tmp_bytes, counts, offsets, (int)(n + 1)));
             DB_TRY(hipMemcpy(&extra, offsets + n, 4, hipMemcpyDeviceToHost));
         }
@@ -859,7 +911,7 @@ int build_impl(const std::vector<DeviceMeshPart>& parts, const DeviceBuildOption
     const uint32_t R = (uint32_t)nrefs;
     const size_t max_t = R / (kSmall + 1u) + 2u, max_c = R / kChunk + max_t + 2u, small_cap = R / 8u + 1024u;
     size_t bytes2 = padded<float>(6 * (size_t)R) + 3 * padded<uint32_t>(R) + padded<Node2>(R) + 2 * padded<Task>(max_t) + padded<Task>(small_cap) + 2 * padded<uint32_t>(max_t * kBinWords) +
-                    padded<uint32_t>(max_t * 96u) + padded<SplitInfo>(max_t) + padded<uint32_t>(max_t + 1) + 3 * padded<uint32_t>(max_c) + padded<uint32_t>(max_c * 96u) + (1u << 16);
+                    padded<uint32_t>(max_t * 96u) + padded<SplitInfo>(max_t) + padded<uint32_t>(max_t + 1) + 4 * padded<uint32_t>(max_c) + padded<uint32_t>(max_c * 96u) + (1u << 16);
     DB_TRY(a2.reserve(bytes2));
     sw.lap("allocation (phase 2)");
     float* ref_box = a2.take<float>(6 * (size_t)R); uint32_t* ref_tri = a2.take<uint32_t>(R);
@@ -868,7 +920,7 @@ int build_impl(const std::vector<DeviceMeshPart>& parts, const DeviceBuildOption
     Task* tasks[2] = {a2.take<Task>(max_t), a2.take<Task>(max_t)}; Task* small = a2.take<Task>(small_cap);
     uint32_t* gmn = a2.take<uint32_t>(max_t * kBinWords); uint32_t* gmx = a2.take<uint32_t>(max_t * kBinWords); uint32_t* gcnt = a2.take<uint32_t>(max_t * 96u);
     SplitInfo* split = a2.take<SplitInfo>(max_t); uint32_t* chunk_base = a2.take<uint32_t>(max_t + 1);
-    uint32_t* chunk_task = a2.take<uint32_t>(max_c); uint32_t* chunk_off = a2.take<uint32_t>(max_c); uint32_t* scan_tmp = a2.take<uint32_t>(max_c);
+    uint32_t* chunk_task = a2.take<uint32_t>(max_c); uint32_t* chunk_off = a2.take<uint32_t>(max_c); uint32_t* scan_tmp = a2.take<uint32_t>(max_c); uint32_t* chunk_lefts = a2.take<uint32_t>(max_c);
     uint32_t* chunk_cnt = a2.take<uint32_t>(max_c * 96u);
     if (!chunk_cnt) { err = "device BLAS build: arena overflow (phase 2)"; return NRAYS_ERR_OOM; }
     if (do_split) hipLaunchKernelGGL(k_presplit<kModeEmit>, dim3(split_grid), dim3(256), 0, 0, recs, tbox, (uint32_t)n, thr, frames, counts, offsets, hist, ref_box, ref_tri);
@@ -895,7 +947,8 @@ int build_impl(const std::vector<DeviceMeshPart>& parts, const DeviceBuildOption
         hipLaunchKernelGGL(k_bin, dim3(nchunks), dim3(256), 0, 0, tasks[cur], nt, chunk_base, chunk_task, order0, order1, ref_box, gmn, gmx, gcnt, chunk_cnt);
         hipLaunchKernelGGL(k_select, dim3((nt + 3u) / 4u), dim3(256), 0, 0, tasks[cur], nt, gmn, gmx, gcnt, split, tasks[cur ^ 1], small, (uint32_t)small_cap, node2, order0, order1, order0,
                            ref_box, ctr, max_leaf, prim_cost);
-        hipLaunchKernelGGL(k_part_scan, dim3(1), dim3(1024), 0, 0, chunk_task, chunk_base, chunk_cnt, split, nchunks, chunk_off, scan_tmp);
+        hipLaunchKernelGGL(k_chunk_lefts, dim3((nchunks + 255u) / 256u), dim3(256), 0, 0, chunk_task, chunk_cnt, split, nchunks, chunk_lefts);
+        hipLaunchKernelGGL(k_part_scan, dim3(1), dim3(1024), 0, 0, chunk_task, chunk_base, chunk_lefts, nchunks, chunk_off, scan_tmp);
         hipLaunchKernelGGL(k_scatter, dim3(nchunks), dim3(256), 0, 0, tasks[cur], chunk_task, chunk_base, chunk_off, split, order0, order1, ref_box);
         DB_TRY(hipMemcpy(&nt, &ctr->n_next, 4, hipMemcpyDeviceToHost));
         cur ^= 1; ++levels;
