@@ -16,7 +16,7 @@ import __graft_entry__ as g  # noqa: E402
 
 
 def main():
-    out = os.path.join(ROOT, "nrays_amd", "lib", "libnrays_hip.so")
+    out = os.path.join(ROOT, "nrays_amd", "lib", "ab", "kres.so")  # never the product library: a failed link must not clobber it
     extra, isa = [], False
     args = sys.argv[1:]
     while args:
@@ -29,7 +29,7 @@ def main():
             extra.append(a)
     os.makedirs(os.path.dirname(out), exist_ok=True)
     srcs = [os.path.join(g.CSRC, s) for s in g.HIP_SOURCES]
-    cmd = ["/opt/rocm/bin/hipcc"] + g.HIP_FLAGS + extra + ["-Rpass-analysis=kernel-resource-usage", "-o", out] + srcs + g.HIP_LINK
+    cmd = ["/opt/rocm/bin/hipcc"] + g.HIP_FLAGS + extra + ["-Rpass-analysis=kernel-resource-usage", "-shared", "-o", out] + srcs + g.HIP_LINK
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         print(r.stdout[-4000:])
