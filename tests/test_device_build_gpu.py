@@ -153,3 +153,23 @@ def test_device_built_scenes_render_the_host_built_frame(gpu, monkeypatch, scene
         assert gst["node_tests"] == wst["node_tests"] and gst["tri_tests"] == wst["tri_tests"], (gst, wst)
     else:
         assert abs(gst["node_tests"] - wst["node_tests"]) <= 0.05 * wst["node_tests"], (gst["node_tests"], wst["node_tests"])
+
+
+def test_full_size_hairball_tree_is_the_host_tree(gpu):
+    """BASELINE config 5's mesh at full size (the 2.88 M-triangle stand-in, pre-split into 23 M references): the device builder's 4.9 M
+    4-wide nodes equal the host builder's bit for bit, and every leaf holds the same triangles (compared through per-leaf sums of the
+    triangle ids and of their squares: the order inside a leaf is free)."""
+    pts, idx, _ = standins.hairball_geometry()
+    pts = (np.asarray(pts, np.float32) * np.float32(0.25)).astype(np.float32)
+    d, h = _build(pts, idx, True, presplit=True), _build(pts, idx, False, presplit=True)
+    assert d["hairy"] == h["hairy"] == 1 and d["root"] == h["root"] and d["depth"] == h["depth"]
+    assert d["nodes"].shape == h["nodes"].shape and len(d["nodes"]) > 4_000_000 and len(d["tri"]) == len(h["tri"]) > 20_000_000
+    assert np.array_equal(np.delete(h["nodes"], np.s_[8:12], axis=1), np.delete(d["nodes"], np.s_[8:12], axis=1))
+    refs = h["nodes"][:, 8:12].view(np.int32)
+    assert np.array_equal(refs, d["nodes"][:, 8:12].view(np.int32))
+    leaf = refs[(refs < 0) & (refs != -2**31)]
+    starts = np.sort((~leaf).astype(np.uint32) >> 3).astype(np.int64)
+    assert starts[0] == 0 and len(np.unique(starts)) == len(starts)
+    hs, ds = h["tri"].astype(np.int64), d["tri"].astype(np.int64)
+    assert np.array_equal(np.add.reduceat(hs, starts), np.add.reduceat(ds, starts))
+    assert np.array_equal(np.add.reduceat(hs * hs, starts), np.add.reduceat(ds * ds, starts))
