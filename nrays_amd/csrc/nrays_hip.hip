@@ -1545,6 +1545,8 @@ int nrays_debug_tile_costs(NraysScene* sc, uint32_t* out, uint32_t capacity, uin
     *out_count = n;
     return NRAYS_OK;
 }
+#endif
+#ifdef NR_DEBUG_TILE_COSTS
 // Tuning builds only (tools/wave_timeline.py): {kernel entry, first tile, exit, tiles} per wave of the last primary launch, 10 ns ticks.
 int nrays_debug_wave_times(NraysScene* sc, uint32_t* out, uint32_t capacity_waves, uint32_t* out_waves) {
     if (!sc || !sc->have_last || !sc->d_wave_times) return NRAYS_ERR_BAD_ARG;
