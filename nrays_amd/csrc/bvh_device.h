@@ -21,6 +21,7 @@ struct DeviceMeshPart { // one TriMesh node of the group sharing a BLAS
 
 struct DeviceBlas {
     BvhNode* nodes = nullptr; size_t num_nodes = 0; // device memory; child refs already absolute (node_base / prim_base applied)
+    size_t node_capacity = 0;                        // nodes the allocation holds (>= num_nodes: room for the scene's host-built nodes behind them)
     TriRec* tris = nullptr; TriUv* uvs = nullptr; size_t num_refs = 0; // device memory, leaf order
     int32_t root = kEmptyChild;
     float mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0}; // local bounds of the triangles
@@ -34,6 +35,7 @@ struct DeviceBuildOptions {
     float prim_cost = 0.5f, prim_cost_hairy = 0.7f;
     double budget = 1.0, budget_hairy = 5.0, min_gain = 0.5, min_gain_hairy = 0.05, hairy_emptiness = 0.9;
     bool presplit = true;
+    size_t node_tail = 16384; // spare node slots behind the BLAS: a scene with ONE device-built BLAS adopts its arrays as they are (no second copy of GBs)
 };
 
 // Builds the BLAS of `parts` on the current device.  Returns NRAYS_OK or a negative NraysStatus with `err` set.

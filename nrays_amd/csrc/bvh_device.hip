@@ -1004,8 +1004,8 @@ int build_impl(const std::vector<DeviceMeshPart>& parts, const DeviceBuildOption
         const uint32_t s = level_start[l], e = l + 1 < level_start.size() ? level_start[l + 1] : n4;
         if (e > s) hipLaunchKernelGGL(k_sizes_level, dim3((e - s + 255u) / 256u), dim3(256), 0, 0, tmp, s, e);
     }
-    DB_TRY(hipMalloc((void**)&out.nodes, (size_t)n4 * sizeof(BvhNode)));
-    out.num_nodes = n4;
+    DB_TRY(hipMalloc((void**)&out.nodes, ((size_t)n4 + opt.node_tail) * sizeof(BvhNode)));
+    out.num_nodes = n4; out.node_capacity = (size_t)n4 + opt.node_tail;
     for (size_t l = 0; l < level_start.size(); ++l) {
         const uint32_t s = level_start[l], e = l + 1 < level_start.size() ? level_start[l + 1] : n4;
         if (e > s) hipLaunchKernelGGL(k_emit_level, dim3((e - s + 255u) / 256u), dim3(256), 0, 0, tmp, s, e, out.nodes, node_base, prim_base);
@@ -1034,7 +1034,7 @@ void free_device_blas(DeviceBlas& b) {
     if (b.nodes) (void)hipFree(b.nodes);
     if (b.tris) (void)hipFree(b.tris);
     if (b.uvs) (void)hipFree(b.uvs);
-    b.nodes = nullptr; b.tris = nullptr; b.uvs = nullptr; b.num_nodes = 0; b.num_refs = 0;
+    b.nodes = nullptr; b.tris = nullptr; b.uvs = nullptr; b.num_nodes = 0; b.num_refs = 0; b.node_capacity = 0;
 }
 
 } // namespace nrays

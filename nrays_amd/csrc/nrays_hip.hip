@@ -1276,7 +1276,18 @@ int nrays_scene_create(const NraysSceneDesc* desc, NraysScene** out_scene) {
     HostScene& h = sc->host;
     const auto t_create1 = std::chrono::steady_clock::now();
     std::memset(&sc->d, 0, sizeof sc->d);
-    {
+    if (h.dev_blas.size() == 1 && h.tris.empty() && h.triuvs.empty() && h.dev_blas[0].nodes && h.dev_blas[0].num_nodes + h.nodes.size() <= h.dev_blas[0].node_capacity) {
+        // ONE device-built BLAS and nothing but TLAS nodes from the host (a single large mesh): the builder's arrays ARE the scene's arrays — the host
+        // nodes go into the spare slots behind the BLAS; no second allocation, no copy and no release of gigabytes (0.2 s for the hairball stand-in)
+        nrays::DeviceBlas& b = h.dev_blas[0];
+        if (!h.nodes.empty() && hipMemcpy(b.nodes + b.num_nodes, h.nodes.data(), h.nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice) != hipSuccess)
+            return bail(fail(NRAYS_ERR_HIP, "upload of the TLAS nodes failed"));
+        sc->d.nodes = b.nodes; sc->d.tris = b.tris; sc->d.triuvs = b.uvs;
+        sc->allocs.push_back(b.nodes); sc->allocs.push_back(b.tris); sc->allocs.push_back(b.uvs);
+        sc->scene_bytes += (b.num_nodes + h.nodes.size()) * sizeof(BvhNode) + b.num_refs * (sizeof(TriRec) + sizeof(TriUv));
+        b.nodes = nullptr; b.tris = nullptr; b.uvs = nullptr;
+        h.dev_blas.clear();
+    } else {
         std::vector<std::pair<const BvhNode*, size_t>> nseg; std::vector<std::pair<const TriRec*, size_t>> tseg; std::vector<std::pair<const TriUv*, size_t>> useg;
         for (const nrays::DeviceBlas& b : h.dev_blas) { nseg.push_back({b.nodes, b.num_nodes}); tseg.push_back({b.tris, b.num_refs}); useg.push_back({b.uvs, b.num_refs}); }
         if ((rc = upload_joined(sc, nseg, h.nodes, &sc->d.nodes)) != NRAYS_OK) return bail(rc);
