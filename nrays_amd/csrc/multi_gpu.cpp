@@ -339,7 +339,7 @@ int nrays_render_multi_device(NraysSceneSet* s, const NraysRenderParams* params,
         if (any_rccl && !c->comms.empty()) {
             MG_NCCL(ncclGroupStart());
             // Between ncclGroupStart and ncclGroupEnd nothing may return: the first failure is remembered, the group is ALWAYS
-            // closed, and a failed exchange aborts the communicators (poison) so that neither a retry nor the peers hang.
+            // closed, and a failed exchange aborts THIS process's communicators (poison): a retry fails fast; peer processes time out or are aborted by their own process.
             int group_rc = NRAYS_OK; std::string group_msg;
             auto hip_ok = [&](hipError_t e, const char* what) { if (e != hipSuccess && group_rc == NRAYS_OK) { group_rc = NRAYS_ERR_HIP; group_msg = std::string(what) + ": " + hipGetErrorString(e); } return e == hipSuccess; };
             auto nccl_ok = [&](ncclResult_t r, const char* what) { if (r != ncclSuccess && group_rc == NRAYS_OK) { group_rc = NRAYS_ERR_RCCL; group_msg = std::string(what) + ": " + ncclGetErrorString(r); } return r == ncclSuccess; };

@@ -452,6 +452,9 @@ __global__ void __launch_bounds__(kBlock, OCC ? NR_OCC3_AS : waves_per_simd(FEAT
     flush_counters(ctr, cnt, STATS);
 }
 
+// Value range of the fixed-point sums (2^-32 units in a signed 64-bit integer): a contribution is clamped to +-9.0e18 units (|x| <= 2.1e9 — colours
+// are O(1)), a NaN contribution counts as 0 (the float atomicAdd it replaced would have poisoned the pixel; the reference's f32 sum too), and a sum of
+// several clamped contributions can wrap — none of which a frame of finite O(1) radiances can reach.
 __device__ __forceinline__ long long to_fixed(float x) {
     double v = (double)x * 4294967296.0;
     v = v > 9.0e18 ? 9.0e18 : (v < -9.0e18 ? -9.0e18 : v); // (NaN -> 0 below)
@@ -946,6 +949,8 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
             HIP_TRY(hipMemsetAsync(sc->d_fixed, 0, slots * sizeof(long long), stream)); // k_fold_fixed leaves it cleared
             sc->fixed_slots = slots;
         }
+        // a frame that failed between its k_bounce rounds and k_fold_fixed left sums behind: they must not reach this frame
+        if (sc->fixed_dirty) { HIP_TRY(hipMemsetAsync(sc->d_fixed, 0, sc->fixed_slots * sizeof(long long), stream)); sc->fixed_dirty = false; }
     }
     if (sc->spill_entries && !sc->d_spill) {
         HIP_TRY(hipMalloc((void**)&sc->d_spill, (size_t)kMaxGrid * kBlock * sc->spill_entries * sizeof(uint32_t)));
@@ -1218,13 +1223,13 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
             if (instrumented) hipLaunchKernelGGL(k_bounce<true>, dim3(grid), dim3(kBlock), 0, stream, sc->d, sc->queue[r & 1].q, sc->d_counts + r, sc->queue_capacity, qn, sc->d_fixed, sc->d_counters, sc->d_spill, p->max_depth);
             else hipLaunchKernelGGL(k_bounce<false>, dim3(grid), dim3(kBlock), 0, stream, sc->d, sc->queue[r & 1].q, sc->d_counts + r, sc->queue_capacity, qn, sc->d_fixed, sc->d_counters, sc->d_spill, p->max_depth);
             HIP_TRY(hipGetLastError());
-            folded = false;
+            folded = false; sc->fixed_dirty = true;
         }
         if (queued && !folded) { // the next batch's k_primary continues the running sums in d_out: fold this batch's queued chains in first
             const size_t n = (size_t)npix_local * 3;
             hipLaunchKernelGGL(k_fold_fixed, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_out, sc->d_fixed, n);
             HIP_TRY(hipGetLastError());
-            folded = true;
+            folded = true; sc->fixed_dirty = false;
         }
     }
     } // !staged

@@ -43,6 +43,7 @@ struct NraysScene {
     uint64_t launch_index = 0, frame_index = 0;
     uint32_t* d_spill = nullptr;
     long long* d_fixed = nullptr; size_t fixed_slots = 0; // per-pixel fixed-point sums of the queued chains (double-branching scenes)
+    bool fixed_dirty = false; // k_bounce rounds were enqueued and their k_fold_fixed was not (an error in between): cleared at the next frame's start
     double* d_tables = nullptr; size_t tables_doubles = 0; // raygen tables: 4 * (width + height) f64
     uint32_t tab_w = 0, tab_h = 0; double tab_m[16] = {0}; bool tab_valid = false;
     // previous frame's wave-tile costs (k_primary) and the order derived from them (k_tile_order); valid for one
