@@ -313,7 +313,7 @@ def single_gpu_measure(name, W, H, steps, warmup, args, pmc=True, moving=True):
            "rays_traced_per_frame": int(plain.rays_traced()),
            "value_traced": round(plain.rays_traced() * steps / dt / 1e6, 3),
            "scene_build_s": round(scene_build_s, 4),
-           "scene_build_note": "nrays_scene_create as the caller sees it; BLASes of >= 50 000 triangles are built on the GPU (nrays_amd/csrc/bvh_device.hip), smaller ones and the TLASes on the host",
+           "scene_build_note": "nrays_scene_create as the caller sees it; BLASes of >= 2 000 triangles are built on the GPU (nrays_amd/csrc/bvh_device.hip), smaller ones and the TLASes on the host",
            "cold_frame_ms": round(first[0], 4), "second_frame_ms": round(first[1], 4), "third_frame_ms": round(first[2], 4),
            "cold_frame_note": "fresh handle in a warm process (kernels loaded): first scene::render of a camera — no cost history, cost "
                               "recording, raygen tables, per-handle buffer allocation; host-synchronised wall time"}

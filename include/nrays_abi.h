@@ -280,7 +280,7 @@ int nrays_debug_scene_flags(const NraysScene* scene, uint32_t out[2]);
 
 /* Test probe of `Scene::new`'s BVT construction for one TriMesh (src/scene.rs:119-133; ncollide's BVT::new_balanced inside TriMesh::new,
  * examples/loader3d.rs:695): builds the BLAS of `mesh` with the host builder (flags bit 0 clear) or the device builder (bit 0 set;
- * nrays_scene_create picks it for meshes from NRAYS_GPU_BUILD_MIN triangles, default 50 000), bit 1 = without triangle pre-splitting,
+ * nrays_scene_create picks it for meshes from NRAYS_GPU_BUILD_MIN triangles, default 2 000), bit 1 = without triangle pre-splitting,
  * and copies it out: `nodes` = num_nodes x 32 floats (the 128-byte 4-wide node: planes by slot, child refs in slot 2, local
  * indices, depth-first order), `tri_ids` = the triangle index behind each of the num_refs leaf slots.  Both builders apply the same
  * split rule with the same arithmetic, so from the same references they return the same nodes.  The caller provides the buffers

@@ -280,11 +280,11 @@ static bool presplit(const std::vector<TriRec>& recs, std::vector<PrimBounds>& r
 #define NR_MAX_LEAF 8
 #endif
 // Triangle count from which a BLAS is built on the GPU (bvh_device.hip); NRAYS_GPU_BUILD=0: never, NRAYS_GPU_BUILD_MIN=n: from n triangles.
-// Below ~50 k triangles the host builder's few milliseconds are less than the device path's allocations and round trips.
+// Crossover on MI355X (tools/build_crossover.py, profiles/r04_build_crossover.log): 1 000 triangles host 1.6 / device 2.1 ms, 3 000: 3.9 / 2.5, 50 000: 65 / 3.6, 1 M: 337 / 15.
 static size_t device_build_min() { // read per scene (not cached): tests and A/B runs flip it between two nrays_scene_create calls
     if (const char* e = getenv("NRAYS_GPU_BUILD")) if (atoi(e) == 0) return std::numeric_limits<size_t>::max();
     if (const char* e = getenv("NRAYS_GPU_BUILD_MIN")) return (size_t)std::max(1ll, atoll(e));
-    return (size_t)50000;
+    return (size_t)2000;
 }
 static DeviceBuildOptions device_options(bool presplit_on) {
     DeviceBuildOptions o;
