@@ -268,8 +268,8 @@ enum { kModeCount = 0, kModeHist = 1, kModeEmit = 2 };
 // One thread walks the split tree of one triangle exactly like split_rec() of scene_build.cpp (low half first; the high half's
 // reference slot is reserved when the split happens).  kModeHist also files the empty area of every split; kModeEmit writes boxes.
 template <int MODE>
-__global__ __launch_bounds__(256) void k_presplit(const TriRec* recs, const float* tbox, uint32_t n, double thr, SplitFrame* frames, uint32_t* counts,
-                                                  const uint32_t* offsets, uint32_t* hist, float* ref_box, uint32_t* ref_tri) {
+__global__ __launch_bounds__(256) void k_presplit(const TriRec* recs, const float* tbox, uint32_t n, double thr, int depth_cap, SplitFrame* frames, uint32_t* counts,
+                                                  const uint32_t* offsets, uint32_t* hist, float* ref_box, uint32_t* ref_tri, uint32_t* capped) {
     SplitFrame* stack = frames + (size_t)(blockIdx.x * 256u + threadIdx.x) * (kSplitDepthMax + 1);
     for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < n; t += gridDim.x * 256u) {
         ClipPoly cur; PrimBounds box; int slot = -1, depth = 0, sp = 0, next = 0;
@@ -279,7 +279,9 @@ __global__ __launch_bounds__(256) void k_presplit(const TriRec* recs, const floa
             const double ha = box_half_area(box);
             const double gain = ha - poly_area2(cur);
             ClipPoly lo, hi; PrimBounds bl, bh;
-            if (depth >= kSplitDepthMax || !piece_qualifies(ha, gain, thr) || !split_piece(cur, box, lo, hi, bl, bh)) {
+            // depth_cap < kSplitDepthMax: the survey pass of the host code below (a piece that would still be split there is reported through `capped`)
+            if (MODE == kModeHist && depth >= depth_cap && depth < kSplitDepthMax && piece_qualifies(ha, gain, thr)) *capped = 1u;
+            if (depth >= depth_cap || !piece_qualifies(ha, gain, thr) || !split_piece(cur, box, lo, hi, bl, bh)) {
                 if (MODE == kModeEmit) {
                     const size_t r = slot < 0 ? (size_t)t : (size_t)n + offsets[t] + (uint32_t)slot;
                     for (int a = 0; a < 3; ++a) { ref_box[6 * r + a] = box.mn[a]; ref_box[6 * r + 3 + a] = box.mx[a]; }
@@ -881,26 +883,41 @@ int build_impl(const std::vector<DeviceMeshPart>& parts, const DeviceBuildOption
         hairy = total_area > 0.0 && (total_area - total_tri2) > opt.hairy_emptiness * total_area;
         const double min_gain = (hairy ? opt.min_gain_hairy : opt.min_gain) * total_area / (double)n;
         const size_t budget = (size_t)((hairy ? opt.budget_hairy : opt.budget) * (double)n);
-        DB_TRY(hipMemset(hist, 0, kHistBins * sizeof(uint32_t)));
-        hipLaunchKernelGGL(k_presplit<kModeHist>, dim3(split_grid), dim3(256), 0, 0, recs, tbox, (uint32_t)n, min_gain, frames, counts, offsets, hist, (float*)nullptr, (uint32_t*)nullptr);
-        size_t tmp_bytes = cub_bytes;
-        DB_TRY(hipcub::DeviceScan::ExclusiveSum(cub_tmp1, tmp_bytes, counts, offsets, (int)(n + 1)));
-        uint32_t extra = 0;
-        DB_TRY(hipMemcpy(&extra, offsets + n, 4, hipMemcpyDeviceToHost));
-        thr = min_gain;
-        if ((size_t)extra > budget) { // the budget binds: the threshold is the empty area below which the budget-th largest split falls
-            std::vector<uint32_t> h(kHistBins);
-            DB_TRY(hipMemcpy(h.data(), hist, kHistBins * sizeof(uint32_t), hipMemcpyDeviceToHost));
-            size_t cum = 0; uint32_t b = kHistBins;
-            while (b > 0 && cum + h[b - 1] <= budget) { cum += h[b - 1]; --b; } // bins >= b fit in the budget
-            uint32_t bits = b << kHistShift; float edge; std::memcpy(&edge, &bits, 4);
-            thr = std::max(min_gain, (double)edge);
-            // (float)gain rounds to nearest: a piece just below the edge may have been filed above it; `gain > thr` is what both passes below apply
-            hipLaunchKernelGGL(k_presplit<kModeCount>, dim3(split_grid), dim3(256), 0, 0, recs, tbox, (uint32_t)n, thr, frames, counts, offsets, hist, (float*)nullptr, (uint32_t*)nullptr);
-            tmp_bytes = cub_bytes;
+        // Survey pass: every piece split against min_gain, but at most kSurveyDepth levels deep (a handful of huge degenerate triangles among small
+        // ones would otherwise make single threads walk up to 2^20 pieces each before the budget is even known), with a histogram of the empty
+        // areas of the splits.  If nothing was cut short and the count fits the budget, that is the answer.  Otherwise the threshold the budget
+        // amounts to is read off the histogram and the split trees are walked again, full depth, against it — each such pass files its own
+        // histogram, so a second correction (the first histogram missed what lay below the survey depth) lands within a bin of the budget.
+        constexpr int kSurveyDepth = 10;
+        uint32_t* capped = &ctr->pad;
+        uint32_t extra = 0; thr = min_gain;
+        auto pass = [&](double t, int cap) -> int {
+            DB_TRY(hipMemset(hist, 0, kHistBins * sizeof(uint32_t)));
+            DB_TRY(hipMemset(capped, 0, 4));
+            hipLaunchKernelGGL(k_presplit<kModeHist>, dim3(split_grid), dim3(256), 0, 0, recs, tbox, (uint32_t)n, t, cap, frames, counts, offsets, hist, (float*)nullptr, (uint32_t*)nullptr, capped);
+            size_t tmp_bytes = cub_bytes;
             DB_TRY(hipcub::DeviceScan::ExclusiveSum(cub_tmp1, tmp_bytes, counts, offsets, (int)(n + 1)));
             DB_TRY(hipMemcpy(&extra, offsets + n, 4, hipMemcpyDeviceToHost));
+            return NRAYS_OK;
+        };
+        { const int rc = pass(min_gain, kSurveyDepth); if (rc != NRAYS_OK) return rc; }
+        uint32_t was_capped = 0;
+        DB_TRY(hipMemcpy(&was_capped, capped, 4, hipMemcpyDeviceToHost));
+        bool exact = !was_capped; // `counts` describe the full-depth walk against `thr`
+        for (int round = 0; round < 6 && ((size_t)extra > budget || !exact); ++round) {
+            if ((size_t)extra > budget) { // the budget binds: the threshold is the empty area below which the budget-th largest split falls
+                std::vector<uint32_t> h(kHistBins);
+                DB_TRY(hipMemcpy(h.data(), hist, kHistBins * sizeof(uint32_t), hipMemcpyDeviceToHost));
+                size_t cum = 0; uint32_t b = kHistBins;
+                while (b > 0 && cum + h[b - 1] <= budget) { cum += h[b - 1]; --b; } // bins >= b fit in the budget
+                uint32_t bits = b << kHistShift; float edge; std::memcpy(&edge, &bits, 4);
+                // (float)gain rounds to nearest: a piece just below the edge may have been filed above it; `gain > thr` is what every pass applies
+                thr = std::max(std::max(min_gain, (double)edge), round ? thr * 1.05 : 0.0); // (strictly rising: the loop ends)
+            }
+            const int rc = pass(thr, kSplitDepthMax); if (rc != NRAYS_OK) return rc;
+            exact = true;
         }
+        if ((size_t)extra > 2 * budget + 1024) { err = "device BLAS build: pre-splitting does not settle on its budget"; return NRAYS_ERR_HIP; }
         nrefs = n + extra; do_split = extra > 0;
     }
     out.hairy = hairy;
@@ -923,7 +940,7 @@ int build_impl(const std::vector<DeviceMeshPart>& parts, const DeviceBuildOption
     uint32_t* chunk_task = a2.take<uint32_t>(max_c); uint32_t* chunk_off = a2.take<uint32_t>(max_c); uint32_t* scan_tmp = a2.take<uint32_t>(max_c); uint32_t* chunk_lefts = a2.take<uint32_t>(max_c);
     uint32_t* chunk_cnt = a2.take<uint32_t>(max_c * 96u);
     if (!chunk_cnt) { err = "device BLAS build: arena overflow (phase 2)"; return NRAYS_ERR_OOM; }
-    if (do_split) hipLaunchKernelGGL(k_presplit<kModeEmit>, dim3(split_grid), dim3(256), 0, 0, recs, tbox, (uint32_t)n, thr, frames, counts, offsets, hist, ref_box, ref_tri);
+    if (do_split) hipLaunchKernelGGL(k_presplit<kModeEmit>, dim3(split_grid), dim3(256), 0, 0, recs, tbox, (uint32_t)n, thr, kSplitDepthMax, frames, counts, offsets, hist, ref_box, ref_tri, (uint32_t*)nullptr);
     else hipLaunchKernelGGL(k_iota_refs, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, 0, (uint32_t)n, tbox, ref_box, ref_tri);
     sw.lap("reference boxes");
     const float prim_cost = hairy ? opt.prim_cost_hairy : opt.prim_cost;

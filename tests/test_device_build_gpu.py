@@ -173,3 +173,39 @@ def test_full_size_hairball_tree_is_the_host_tree(gpu):
     hs, ds = h["tri"].astype(np.int64), d["tri"].astype(np.int64)
     assert np.array_equal(np.add.reduceat(hs, starts), np.add.reduceat(ds, starts))
     assert np.array_equal(np.add.reduceat(hs * hs, starts), np.add.reduceat(ds * ds, starts))
+
+
+def test_degenerate_and_huge_triangles_do_not_derail_the_build(gpu, monkeypatch):
+    """A soup of small triangles with a few enormous thin diagonal ones (and points, lines): pre-splitting rates pieces by their EMPTY box
+    area, so each of the enormous ones alone could be cut 2^20 times against the small average; the device builder's survey pass is depth-
+    capped and its threshold iterates onto the budget (the host builder is budget-bound by its heap).  The build must stay within the budget,
+    every triangle must stay reachable, and the scene must render the host-built frame."""
+    import time
+    import torch
+    rng = np.random.default_rng(11)
+    pts, idx = _soup(6000, 21, 1.0, 0.01)
+    big = []
+    for k in range(24):  # thin slivers across the whole scene, two of them degenerate (a line, a point)
+        a = rng.uniform(-40, 40, 3); b = a + rng.uniform(-80, 80, 3); c = a + (b - a) * 0.5 + rng.uniform(-1e-3, 1e-3, 3)
+        if k == 0: c = b
+        if k == 1: b = a; c = a
+        big += [a, b, c]
+    pts = np.concatenate([pts, np.asarray(big)]).astype(np.float32); idx = np.arange(len(pts), dtype=np.uint32).reshape(-1, 3)
+    t0 = time.time(); d = _build(pts, idx, True, presplit=True); dt = time.time() - t0
+    h = _build(pts, idx, False, presplit=True)
+    assert dt < 2.0, dt
+    assert len(d["tri"]) <= 2 * len(idx) + 1024 + len(idx), (len(d["tri"]), len(idx))  # budget 1.0 per triangle (+ the bin the threshold falls in)
+    assert set(d["tri"].tolist()) == set(range(len(idx))) == set(h["tri"].tolist())
+
+    def make():
+        mat = nr.PhongMaterial((0.1, 0.1, 0.1), (1, 1, 1), (1, 1, 1), None, None, 50.0)
+        node = nr.SceneNode(mat, 0.0, 0.0, 1.0, 1.0, nr.Isometry3((0.0, 0.0, 0.0), (0.0, 0.0, 0.0)), nr.TriMesh(pts.astype(np.float64), idx, None))
+        return nr.Scene([node], [nr.Light((0.0, 3.0, -6.0), 0.0, 1, (1, 1, 1))], (1, 1, 1)), dict(eye=(0.0, 0.5, -6.0), at=(0.0, 0.0, 0.0), fovy=40.0)
+    monkeypatch.setenv("NRAYS_GPU_BUILD", "0")
+    want, wst = _frame(make, 200, 120)
+    monkeypatch.delenv("NRAYS_GPU_BUILD")
+    monkeypatch.setenv("NRAYS_GPU_BUILD_MIN", "1")
+    got, gst = _frame(make, 200, 120)
+    assert np.array_equal(got, want), np.abs(got - want).max()
+    for k in ("rays_primary", "rays_shadow", "hit_records"):
+        assert gst[k] == wst[k], (k, gst[k], wst[k])
