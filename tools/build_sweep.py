@@ -19,7 +19,7 @@ from tools import scenes_util as su, standins
 
 
 def measure(scene_name, w=1920, h=1080, steps=20):
-    make = {"hairball": standins.hairball_scene, "sponza": standins.sponza_scene, "sponza8": lambda: standins.sponza_scene(n_lights=8)}[scene_name]
+    make = {"hairball": standins.hairball_scene, "sponza": standins.sponza_scene, "sponza8": lambda: standins.sponza_scene(n_lights=8), "hair300": lambda: standins.hairball_scene(strands=300)}[scene_name]
     sc, cam = make()
     lib = abi.load_hip_lib()
     torch.cuda.synchronize(); t0 = time.perf_counter()
