@@ -1,15 +1,15 @@
-// bvh_device.hip — the BLAS of a large TriMesh group built on the GPU (see bvh_device.h).
+// bvh_device.hip — the BLAS of a TriMesh group built on the GPU (see bvh_device.h; nrays_scene_create takes this path from 2 000 triangles).
 //
 // Stages (all on the current device, null stream):
 //   1. k_tri_records      triangle records / uvs / f32 boxes from the caller's f64 vertex arrays (+ the f32-exactness checks)
 //   2. k_presplit         pre-splitting of thin diagonal triangles (presplit_clip.h: the host builder's clip arithmetic); the
 //                         threshold a budget amounts to comes from a histogram of the empty areas of ALL pieces instead of the
-//                         host's heap over a sample
+//                         host's heap over a sample (a depth-capped survey pass first, then full-depth passes until the count fits)
 //   3. binned-SAH binary build, the split rule of bvh_build.cpp bit for bit (32 bins on the centroid bounds, three axes, the first
 //      minimum in (axis, bin) order, the SAH leaf criterion):
 //        large nodes (> kSmall references) level by level — k_bin (LDS bins per 1024-reference chunk, merged with encoded
-//        atomics), k_select (one wave per node), k_part_scan + k_scatter (stable partition between two order buffers);
-//        small nodes — k_small: ONE WAVE builds the whole subtree of a node in LDS.
+//        atomics), k_select (one wave per node), k_chunk_lefts + k_part_scan + k_scatter (stable partition between two order buffers);
+//        small nodes — k_small: ONE WAVE builds the whole subtree of a node in LDS (two-reference nodes are decided without bins).
 //      A binary node is stored at index (split position - 1): no allocation, no atomics, deterministic.
 //   4. collapse into the 128-byte 4-wide nodes of device_types.h (the host Collapser's rule) level by level, subtree sizes bottom-up,
 //      then the host builder's depth-first node order top-down, refs rebased to the scene's arrays
@@ -264,9 +264,9 @@ __global__ __launch_bounds__(256) void k_tri_records(PartDev part, TriRec* recs,
 
 // ---- stage 2: pre-splitting ---------------------------------------------------------------------------------------------
 struct SplitFrame { ClipPoly poly; PrimBounds box; int slot; int depth; };
-enum { kModeCount = 0, kModeHist = 1, kModeEmit = 2 };
+enum { kModeHist = 1, kModeEmit = 2 }; // count the extra references of every triangle (+ the histogram of their empty areas) / write the boxes
 // One thread walks the split tree of one triangle exactly like split_rec() of scene_build.cpp (low half first; the high half's
-// reference slot is reserved when the split happens).  kModeHist also files the empty area of every split; kModeEmit writes boxes.
+// reference slot is reserved when the split happens).  kModeHist counts and files the empty area of every split; kModeEmit writes boxes.
 template <int MODE>
 __global__ __launch_bounds__(256) void k_presplit(const TriRec* recs, const float* tbox, uint32_t n, double thr, int depth_cap, SplitFrame* frames, uint32_t* counts,
                                                   const uint32_t* offsets, uint32_t* hist, float* ref_box, uint32_t* ref_tri, uint32_t* capped) {
