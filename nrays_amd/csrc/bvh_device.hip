@@ -92,6 +92,10 @@ __device__ inline int lane_id() { return (int)(threadIdx.x & 63u); }
 __device__ inline float bcast_f(float v, int src) { return __shfl(v, src, 64); }
 __device__ inline uint32_t bcast_u(uint32_t v, int src) { return (uint32_t)__shfl((int)v, src, 64); }
 
+// Bins settle after their first few entries: most updates would not change them — a plain LDS read (same-address reads are a broadcast) filters those out
+// before the atomic (which serialises the lanes that hit one address): k_bin's 1024-reference chunks, large-node levels 37.8 -> 28.8 ms.
+__device__ inline void lds_min(uint32_t* p, uint32_t v) { if (v < *(volatile uint32_t*)p) atomicMin(p, v); }
+__device__ inline void lds_max(uint32_t* p, uint32_t v) { if (v > *(volatile uint32_t*)p) atomicMax(p, v); }
 __device__ inline void load_box(const float* ref_box, uint32_t id, float mn[3], float mx[3]) {
     const float2* p = reinterpret_cast<const float2*>(ref_box + 6 * (size_t)id);
     float2 a = p[0], b = p[1], c = p[2];
@@ -370,8 +374,8 @@ __global__ __launch_bounds__(256) void k_bin(const Task* tasks, uint32_t nt, con
             if (!use[axis]) continue;
             const int idx = axis * 32 + bin_of(ce[axis], tk.cmn[axis], scale[axis]);
             for (int a = 0; a < 3; ++a) {
-                atomicMin(&smn[idx * 6 + a], enc(mn[a])); atomicMin(&smn[idx * 6 + 3 + a], enc(ce[a]));
-                atomicMax(&smx[idx * 6 + a], enc(mx[a])); atomicMax(&smx[idx * 6 + 3 + a], enc(ce[a]));
+                lds_min(&smn[idx * 6 + a], enc(mn[a])); lds_min(&smn[idx * 6 + 3 + a], enc(ce[a]));
+                lds_max(&smx[idx * 6 + a], enc(mx[a])); lds_max(&smx[idx * 6 + 3 + a], enc(ce[a]));
             }
             atomicAdd(&scnt[idx], 1u);
         }
@@ -594,7 +598,7 @@ __global__ __launch_bounds__(256) void k_small(const Task* small, uint32_t ns, c
                 for (int axis = 0; axis < 3; ++axis) {
                     if (!use[axis]) continue;
                     const int idx = axis * 32 + bin_of(ce[axis], cur.cmn[axis], scale[axis]);
-                    for (int a = 0; a < 3; ++a) {
+                    for (int a = 0; a < 3; ++a) { // (no read-before-atomic filter here: a node's few references rarely repeat a bin — measured 37 -> 47 ms)
                         atomicMin(&bmn[idx * 6 + a], enc(mn[a])); atomicMin(&bmn[idx * 6 + 3 + a], enc(ce[a]));
                         atomicMax(&bmx[idx * 6 + a], enc(mx[a])); atomicMax(&bmx[idx * 6 + 3 + a], enc(ce[a]));
                     }
