@@ -207,6 +207,7 @@ __global__ void __launch_bounds__(kBlock, OCC ? NR_OCC3_AS : waves_per_simd(FEAT
     const uint32_t dbg_t_entry = (uint32_t)__builtin_amdgcn_s_memrealtime();
     const unsigned long long dbg_c_entry = __builtin_readcyclecounter();
     uint32_t dbg_t_first = 0u, dbg_tiles = 0u, dbg_work_tiles = 0u, dbg_work_cycles = 0u, dbg_t_last_end = 0u, dbg_row_ticks = 0u, dbg_rows = 0u;
+    uint32_t dbg_work_ticks = 0u, dbg_miss_ticks = 0u, dbg_miss_tiles = 0u, dbg_longest_ticks = 0u; // second record (nrays_debug_wave_times2): 10 ns ticks in work tiles / in tiles that traced nothing
 #endif
     // Sample-major lane mapping of anti-aliased frames (ray_per_pixel >= 2): 2^lane_log2 lanes share ONE pixel and trace
     // its samples side by side, so a wave covers 64 >> lane_log2 pixels (8x4, 4x4, 4x2, 2x2, 2x1, 1x1) instead of 8x8 and
@@ -342,7 +343,8 @@ __global__ void __launch_bounds__(kBlock, OCC ? NR_OCC3_AS : waves_per_simd(FEAT
 #ifdef NR_DEBUG_TILE_COSTS
         const unsigned long long tile_t0 = __builtin_readcyclecounter();
         bool dbg_worked = false;
-        if (dbg_tiles++ == 0u) dbg_t_first = (uint32_t)__builtin_amdgcn_s_memrealtime();
+        const uint32_t dbg_tile_r0 = (uint32_t)__builtin_amdgcn_s_memrealtime();
+        if (dbg_tiles++ == 0u) dbg_t_first = dbg_tile_r0;
 #else
         const unsigned long long tile_t0 = R.tile_cost ? __builtin_readcyclecounter() : 0ULL;
 #endif
@@ -431,6 +433,8 @@ __global__ void __launch_bounds__(kBlock, OCC ? NR_OCC3_AS : waves_per_simd(FEAT
         }
 #ifdef NR_DEBUG_TILE_COSTS
         if (dbg_worked) { dbg_work_tiles++; dbg_work_cycles += (uint32_t)((__builtin_readcyclecounter() - tile_t0) >> 4); dbg_t_last_end = (uint32_t)__builtin_amdgcn_s_memrealtime(); }
+        { const uint32_t dt_ = (uint32_t)__builtin_amdgcn_s_memrealtime() - dbg_tile_r0;
+          if (dbg_worked) { dbg_work_ticks += dt_; if (dt_ > dbg_longest_ticks) dbg_longest_ticks = dt_; } else { dbg_miss_ticks += dt_; dbg_miss_tiles++; } }
 #endif
         if (R.tile_cost && lane == 0u && part == 0u) { // wave cycles spent on this tile, for the next frame's order
             unsigned long long dt = ((__builtin_readcyclecounter() - tile_t0) >> 4) << lsl; // (a light-parallel tile: its first part stands for all)
@@ -447,6 +451,8 @@ __global__ void __launch_bounds__(kBlock, OCC ? NR_OCC3_AS : waves_per_simd(FEAT
         uint32_t* w = R.wave_times + 4u * (blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6));
         uint32_t hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         w[0] = dbg_t_entry; w[1] = R.dbg_mode == 4u ? (dbg_row_ticks & 0xfffffu) | (dbg_rows << 20) : R.dbg_mode == 3u ? dbg_t_last_end : R.dbg_mode == 2u ? (uint32_t)((__builtin_readcyclecounter() - dbg_c_entry) >> 4) : R.dbg_mode ? (dbg_work_cycles & 0x03ffffffu) | (dbg_work_tiles << 26) : dbg_t_first; w[2] = (uint32_t)__builtin_amdgcn_s_memrealtime(); w[3] = dbg_tiles | (xcc_id() << 28) | ((hw & 0xffffu) << 12);
+        uint32_t* w2 = R.wave_times + 4u * (uint32_t)kMaxGrid * (kBlock / 64) + 4u * (blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6));
+        w2[0] = dbg_work_ticks; w2[1] = dbg_miss_ticks; w2[2] = dbg_row_ticks; w2[3] = (dbg_work_tiles & 0xffu) | ((dbg_miss_tiles & 0xffu) << 8) | ((dbg_rows & 0xffu) << 16) | ((dbg_longest_ticks >> 4) << 24);
     }
 #endif
     flush_counters(ctr, cnt, STATS);
@@ -1182,8 +1188,8 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
 #endif
     }
 #ifdef NR_DEBUG_TILE_COSTS
-    if (!sc->d_wave_times) HIP_TRY(hipMalloc((void**)&sc->d_wave_times, (size_t)kMaxGrid * (kBlock / 64) * 4 * sizeof(uint32_t)));
-    HIP_TRY(hipMemsetAsync(sc->d_wave_times, 0, (size_t)kMaxGrid * (kBlock / 64) * 4 * sizeof(uint32_t), stream));
+    if (!sc->d_wave_times) HIP_TRY(hipMalloc((void**)&sc->d_wave_times, (size_t)kMaxGrid * (kBlock / 64) * 8 * sizeof(uint32_t)));
+    HIP_TRY(hipMemsetAsync(sc->d_wave_times, 0, (size_t)kMaxGrid * (kBlock / 64) * 8 * sizeof(uint32_t), stream));
     R.wave_times = sc->d_wave_times; sc->dbg_grid = grid_primary; R.dbg_mode = getenv("NRAYS_DEBUG_WAVE_WORK") ? (uint32_t)atoi(getenv("NRAYS_DEBUG_WAVE_WORK")) : 0u;
 #endif
     if (R.tile_cost) { sc->cost_tiles = lane_log2 ? win_units : win_units * 4u; sc->cost_grid = grid_primary; }
@@ -1569,6 +1575,15 @@ int nrays_debug_wave_times(NraysScene* sc, uint32_t* out, uint32_t capacity_wave
     HIP_TRY(hipStreamSynchronize(sc->last_stream));
     const uint32_t n = std::min<uint32_t>(capacity_waves, sc->dbg_grid * (kBlock / 64));
     HIP_TRY(hipMemcpy(out, sc->d_wave_times, (size_t)n * 4 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    *out_waves = n;
+    return NRAYS_OK;
+}
+// The second record per wave: {ticks in work tiles, ticks in tiles that traced nothing, ticks in background rows, work tiles | miss tiles << 8 | rows << 16 | longest work tile / 16 ticks << 24}.
+int nrays_debug_wave_times2(NraysScene* sc, uint32_t* out, uint32_t capacity_waves, uint32_t* out_waves) {
+    if (!sc || !sc->have_last || !sc->d_wave_times) return NRAYS_ERR_BAD_ARG;
+    HIP_TRY(hipStreamSynchronize(sc->last_stream));
+    const uint32_t n = std::min<uint32_t>(capacity_waves, sc->dbg_grid * (kBlock / 64));
+    HIP_TRY(hipMemcpy(out, sc->d_wave_times + (size_t)kMaxGrid * (kBlock / 64) * 4, (size_t)n * 4 * sizeof(uint32_t), hipMemcpyDeviceToHost));
     *out_waves = n;
     return NRAYS_OK;
 }

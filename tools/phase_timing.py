@@ -1,9 +1,9 @@
 #!/usr/bin/env python
 """Where the wave cycles of the mesh kernels go (GPU box).  Needs a build with -DNR_PHASE_TIMING (tools/kres.py -o
-nrays_amd/lib/ab/lib_pt.so -DNR_PHASE_TIMING): the kernels then accumulate s_memtime differences per wave —
+nrays_amd/lib/v/lib_pt.so -DNR_PHASE_TIMING): the kernels then accumulate s_memtime differences per wave —
 node loops, leaf phases (of which triangle leaves), whole wave — into the counter fields read here.
 
-  NRAYS_HIP_LIB=nrays_amd/lib/ab/lib_pt.so python tools/phase_timing.py sponza hairball
+  NRAYS_HIP_LIB=nrays_amd/lib/v/lib_pt.so python tools/phase_timing.py sponza hairball
 """
 import ctypes as C
 import json

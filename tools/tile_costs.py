@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """How concentrated a mesh frame's work is: distribution of the per-wave-tile cycle counts k_primary records for the
 cost-ordered work lists.  Needs a -DNR_DEBUG_TILE_COSTS (or -DNR_PHASE_TIMING) build, which exports nrays_debug_tile_costs.
-  NRAYS_HIP_LIB=nrays_amd/lib/variants/tc.so python tools/tile_costs.py sponza hairball balls"""
+  NRAYS_HIP_LIB=nrays_amd/lib/v/tc.so python tools/tile_costs.py sponza hairball balls"""
 import ctypes as C, json, os, sys
 os.environ.setdefault("NRAYS_LPT_ANALYTIC", "1")  # analytic scenes only record tile costs with their (rejected) cost-ordered lists on
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """When the waves of the primary kernel start, reach their first tile and exit (GPU box; needs a -DNR_DEBUG_TILE_COSTS build):
-  NRAYS_HIP_LIB=nrays_amd/lib/variants/tc.so python tools/wave_timeline.py balls [frames]
+  NRAYS_HIP_LIB=nrays_amd/lib/v/tc.so python tools/wave_timeline.py balls [frames]
 Prints the span of the launch (first entry -> last exit), percentiles of the waves' entry / first-tile / exit times relative to the
 first entry, and the tiles of the waves that exit last."""
 import ctypes as C, json, os, sys
