@@ -207,7 +207,7 @@ __global__ void __launch_bounds__(kBlock, OCC ? NR_OCC3_AS : waves_per_simd(FEAT
     const uint32_t dbg_t_entry = (uint32_t)__builtin_amdgcn_s_memrealtime();
     const unsigned long long dbg_c_entry = __builtin_readcyclecounter();
     uint32_t dbg_t_first = 0u, dbg_tiles = 0u, dbg_work_tiles = 0u, dbg_work_cycles = 0u, dbg_t_last_end = 0u, dbg_row_ticks = 0u, dbg_rows = 0u;
-    uint32_t dbg_work_ticks = 0u, dbg_miss_ticks = 0u, dbg_miss_tiles = 0u, dbg_longest_ticks = 0u; // second record (nrays_debug_wave_times2): 10 ns ticks in work tiles / in tiles that traced nothing
+    uint32_t dbg_slow_row = 0u, dbg_work_ticks = 0u, dbg_miss_ticks = 0u, dbg_miss_tiles = 0u, dbg_longest_ticks = 0u; // second record (nrays_debug_wave_times2): 10 ns ticks in work tiles / in tiles that traced nothing
 #endif
     // Sample-major lane mapping of anti-aliased frames (ray_per_pixel >= 2): 2^lane_log2 lanes share ONE pixel and trace
     // its samples side by side, so a wave covers 64 >> lane_log2 pixels (8x4, 4x4, 4x2, 2x2, 2x1, 1x1) instead of 8x8 and
@@ -278,7 +278,9 @@ __global__ void __launch_bounds__(kBlock, OCC ? NR_OCC3_AS : waves_per_simd(FEAT
 #ifdef NR_DEBUG_TILE_COSTS
               { const uint32_t tr0 = (uint32_t)__builtin_amdgcn_s_memrealtime();
                 fill_row_inline(rl, (part & 3u) * 64u + lane, kBlock);
-                dbg_row_ticks += (uint32_t)__builtin_amdgcn_s_memrealtime() - tr0; dbg_rows++; }
+                const uint32_t dtr_ = (uint32_t)__builtin_amdgcn_s_memrealtime() - tr0;
+                if (dtr_ >= (dbg_slow_row & 0xfffu)) dbg_slow_row = (rl << 14) | ((part & 3u) << 12) | (dtr_ > 0xfffu ? 0xfffu : dtr_);
+                dbg_row_ticks += dtr_; dbg_rows++; }
 #else
               fill_row_inline(rl, (part & 3u) * 64u + lane, kBlock);
 #endif
@@ -452,7 +454,7 @@ __global__ void __launch_bounds__(kBlock, OCC ? NR_OCC3_AS : waves_per_simd(FEAT
         uint32_t hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         w[0] = dbg_t_entry; w[1] = R.dbg_mode == 4u ? (dbg_row_ticks & 0xfffffu) | (dbg_rows << 20) : R.dbg_mode == 3u ? dbg_t_last_end : R.dbg_mode == 2u ? (uint32_t)((__builtin_readcyclecounter() - dbg_c_entry) >> 4) : R.dbg_mode ? (dbg_work_cycles & 0x03ffffffu) | (dbg_work_tiles << 26) : dbg_t_first; w[2] = (uint32_t)__builtin_amdgcn_s_memrealtime(); w[3] = dbg_tiles | (xcc_id() << 28) | ((hw & 0xffffu) << 12);
         uint32_t* w2 = R.wave_times + 4u * (uint32_t)kMaxGrid * (kBlock / 64) + 4u * (blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6));
-        w2[0] = dbg_work_ticks; w2[1] = dbg_miss_ticks; w2[2] = dbg_row_ticks; w2[3] = (dbg_work_tiles & 0xffu) | ((dbg_miss_tiles & 0xffu) << 8) | ((dbg_rows & 0xffu) << 16) | ((dbg_longest_ticks >> 4) << 24);
+        w2[0] = dbg_work_ticks; w2[1] = R.dbg_mode == 5u ? dbg_slow_row : dbg_miss_ticks; w2[2] = dbg_row_ticks; w2[3] = (dbg_work_tiles & 0xffu) | ((dbg_miss_tiles & 0xffu) << 8) | ((dbg_rows & 0xffu) << 16) | ((dbg_longest_ticks >> 4) << 24);
     }
 #endif
     flush_counters(ctr, cnt, STATS);
