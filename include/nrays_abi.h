@@ -29,7 +29,8 @@
 extern "C" {
 #endif
 
-#define NRAYS_ABI_VERSION 2
+/* Bumped whenever the exported surface grows or a struct changes: 3 = + nrays_debug_blas_build / NraysBlasDump, nrays_multi_get_timings / NraysMultiTimings (round 4). */
+#define NRAYS_ABI_VERSION 3
 
 typedef enum NraysStatus {
     NRAYS_OK = 0,

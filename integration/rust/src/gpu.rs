@@ -336,6 +336,8 @@ unsafe impl Send for GpuScene {} // one handle must not be used from two threads
 
 impl GpuScene {
     pub fn new(scene: &Scene) -> Result<GpuScene, String> {
+        let v = unsafe { nrays_abi_version() };
+        if v != NRAYS_ABI_VERSION { return Err(format!("libnrays_hip.so ABI version {} != {}", v, NRAYS_ABI_VERSION)); }
         let flat = scene.flatten()?;
         let desc = flat.desc();
         let mut raw = ptr::null_mut();

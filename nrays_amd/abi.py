@@ -6,7 +6,7 @@ and types must match include/nrays_abi.h exactly (tests/test_abi.py checks sizes
 import ctypes as C
 import os
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # NraysStatus
 OK = 0

@@ -833,10 +833,13 @@ int build_impl(const std::vector<DeviceMeshPart>& parts, const DeviceBuildOption
     }
     size_t bytes1 = 0;
     for (auto& kv : uploads) bytes1 += padded<char>(kv.second.first);
+    // the per-thread stacks of k_presplit (0.9 GB from 131 k triangles on) exist only if pre-splitting can run at all
+    const bool may_split = opt.presplit && n >= 64 && opt.budget > 0.0;
+    const size_t frame_count = may_split ? (size_t)split_grid * 256u * (kSplitDepthMax + 1) : 1u;
     size_t cub_bytes = 0; // what the prefix sum over the per-triangle reference counts needs
     DB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, cub_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)(n + 1)));
     bytes1 += padded<TriRec>(n) + padded<TriUv>(n) + padded<float>(6 * n) + 2 * padded<double>(nblocks_tri) + padded<Counters>(1) + 2 * padded<uint32_t>(n + 1) +
-              padded<uint32_t>(kHistBins) + padded<SplitFrame>((size_t)split_grid * 256u * (kSplitDepthMax + 1)) + padded<char>(cub_bytes) + 4096;
+              padded<uint32_t>(kHistBins) + padded<SplitFrame>(frame_count) + padded<char>(cub_bytes) + 4096;
     DB_TRY(a1.reserve(bytes1));
     sw.lap("allocation (phase 1)");
     for (auto& kv : uploads) {
@@ -848,7 +851,7 @@ int build_impl(const std::vector<DeviceMeshPart>& parts, const DeviceBuildOption
     double* part_area = a1.take<double>(nblocks_tri); double* part_tri2 = a1.take<double>(nblocks_tri);
     Counters* ctr = a1.take<Counters>(1);
     uint32_t* counts = a1.take<uint32_t>(n + 1); uint32_t* offsets = a1.take<uint32_t>(n + 1); uint32_t* hist = a1.take<uint32_t>(kHistBins);
-    SplitFrame* frames = a1.take<SplitFrame>((size_t)split_grid * 256u * (kSplitDepthMax + 1));
+    SplitFrame* frames = a1.take<SplitFrame>(frame_count);
     void* cub_tmp1 = a1.take<char>(cub_bytes + 16);
     if (!frames || !cub_tmp1) { err = "device BLAS build: arena overflow (phase 1)"; return NRAYS_ERR_OOM; }
     sw.lap("upload of the mesh arrays");
@@ -878,7 +881,7 @@ int build_impl(const std::vector<DeviceMeshPart>& parts, const DeviceBuildOption
 
     // pre-splitting: the rule and the constants of scene_build.cpp: presplit()
     size_t nrefs = n; bool hairy = false; double thr = 0.0; bool do_split = false;
-    if (opt.presplit && n >= 64 && opt.budget > 0.0) {
+    if (may_split) {
         std::vector<double> pa(nblocks_tri), pt(nblocks_tri);
         DB_TRY(hipMemcpy(pa.data(), part_area, nblocks_tri * sizeof(double), hipMemcpyDeviceToHost));
         DB_TRY(hipMemcpy(pt.data(), part_tri2, nblocks_tri * sizeof(double), hipMemcpyDeviceToHost));
@@ -930,7 +933,8 @@ int build_impl(const std::vector<DeviceMeshPart>& parts, const DeviceBuildOption
 
     // ---- phase 2: references, binary build ----
     const uint32_t R = (uint32_t)nrefs;
-    const size_t max_t = R / (kSmall + 1u) + 2u, max_c = R / kChunk + max_t + 2u, small_cap = R / 8u + 1024u;
+    const size_t cap_div = (size_t)std::max(1, opt.debug_cap_div);
+    const size_t max_t = (R / (kSmall + 1u)) / cap_div + 2u, max_c = R / kChunk + max_t + 2u, small_cap = (R / 8u + 1024u) / cap_div + 1u;
     size_t bytes2 = padded<float>(6 * (size_t)R) + 3 * padded<uint32_t>(R) + padded<Node2>(R) + 2 * padded<Task>(max_t) + padded<Task>(small_cap) + 2 * padded<uint32_t>(max_t * kBinWords) +
                     padded<uint32_t>(max_t * 96u) + padded<SplitInfo>(max_t) + padded<uint32_t>(max_t + 1) + 4 * padded<uint32_t>(max_c) + padded<uint32_t>(max_c * 96u) + (1u << 16);
     DB_TRY(a2.reserve(bytes2));

@@ -220,7 +220,7 @@ static void split_rec(const ClipPoly& poly, const PrimBounds& box, uint32_t tri,
     const double ha = box_half_area(box);
     const double gain = ha - poly_area2(poly);
     ClipPoly lo, hi; PrimBounds bl, bh;
-    if (depth >= 20 || !(gain > thr && gain > NR_PRESPLIT_EMPTY * ha) || !split_piece(poly, box, lo, hi, bl, bh)) { store(box); return; }
+    if (depth >= kSplitDepthMax || !(gain > thr && gain > NR_PRESPLIT_EMPTY * ha) || !split_piece(poly, box, lo, hi, bl, bh)) { store(box); return; }
     const long hi_slot = (long)out.box.size();
     out.box.push_back(bh); out.tri.push_back(tri);
     split_rec(lo, bl, tri, thr, depth + 1, root_slot, slot, out);
@@ -298,6 +298,7 @@ static DeviceBuildOptions device_options(bool presplit_on) {
     envd("NRAYS_PRESPLIT_MINGAIN", o.min_gain); envd("NRAYS_PRESPLIT_MINGAIN_HAIRY", o.min_gain_hairy);
     envf("NRAYS_PRIM_COST", o.prim_cost); envf("NRAYS_PRIM_COST_HAIRY", o.prim_cost_hairy);
     if (const char* e = getenv("NRAYS_MAX_LEAF")) o.max_leaf = atoi(e);
+    if (const char* e = getenv("NRAYS_DEBUG_BUILD_CAPS")) o.debug_cap_div = std::max(1, atoi(e));
     return o;
 }
 

@@ -44,6 +44,7 @@ constexpr int park_slots(int feat) {
     return !(feat & kFeatPark) || !(feat & kFeatAlphaShadow) ? 0
          : ((feat & kFeatMultiSample) ? (NR_PARK_CAP < 25 ? NR_PARK_CAP : 25) : (NR_PARK_CAP < 24 ? NR_PARK_CAP : 24));
 }
+static_assert(NR_PARK_CAP == 0 || NR_PARK_CAP >= 14, "shade_hit() parks 14 dwords unconditionally in a kFeatPark permutation: a tuning build needs NR_PARK_CAP = 0 (drop kFeatPark from the launch table) or >= 14");
 constexpr int32_t kParked = (int32_t)0x80000002;   // a lane that yielded its node phase (traverse(): node_quorum); like kEmptyChild / kSentinel not a leaf ref
                                                    // that can occur (first = 2^28 - 1: scene_build.cpp refuses scenes that large)
 

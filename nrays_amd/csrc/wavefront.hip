@@ -905,8 +905,9 @@ static int wf_render_feat(NraysScene* sc, const NraysRenderParams* p, DRender R,
     uint64_t max_paths = 64ull << 20;
     if (sc->wf) max_paths = sc->wf->max_paths; else if (const char* e = getenv("NRAYS_WF_MAX_PATHS")) max_paths = (uint64_t)std::max(4096ll, atoll(e));
     const uint32_t tiles_per_pass = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::max<uint32_t>(nwt, 1u), max_paths / std::max<uint64_t>(paths_per_tile, 1)));
-    // slots: every path of a pass may hit, plus one partly filled block per producer wave
-    const uint64_t slots64 = (((uint64_t)tiles_per_pass * paths_per_tile + kWfBlock - 1) / kWfBlock + (uint64_t)kWfMaxSegs + 1) * kWfBlock;
+    // slots: every path of a pass may hit, plus one partly filled block per producer wave — of the grid this frame launches (every stage
+    // kernel runs on at most grid_full workgroups), not of the largest grid the library knows: that was 0.8 GB per queue for any frame
+    const uint64_t slots64 = (((uint64_t)tiles_per_pass * paths_per_tile + kWfBlock - 1) / kWfBlock + (uint64_t)waves_full + 1) * kWfBlock;
     if (slots64 >= (1ull << 31)) return set_last_error(NRAYS_ERR_UNSUPPORTED, "staged path: pass too large");
     const uint32_t slots = (uint32_t)slots64;
     const size_t acc_floats = spp > 1 ? (size_t)tiles_per_pass * paths_per_tile * 3 : 0;

@@ -20,6 +20,21 @@ def build():
     subprocess.check_call(["make", "-s", "-C", _DIR])
 
 
+def use_native():
+    """bench.py's cpu_baseline leg only: builds the oracle on THIS host with -march=native (a separate file; the portable build the tests
+    use stays as it is) and makes it the library of this process.  Returns True if the native build is now in use."""
+    global _lib, LIB_PATH
+    native = os.path.join(_DIR, "_build", "libnrays_oracle_native.so")
+    try:
+        subprocess.check_call(["make", "-s", "-C", _DIR, "native"])
+    except Exception:
+        return False
+    if not os.path.exists(native):
+        return False
+    LIB_PATH, _lib = native, None
+    return True
+
+
 def lib():
     global _lib
     if _lib is None:

@@ -235,3 +235,56 @@ def test_merged_group_with_and_without_uvs(gpu, monkeypatch):
     for k in ("rays_primary", "rays_shadow", "hit_records", "tex_samples", "node_tests"):
         assert gst[k] == wst[k], (k, gst[k], wst[k])
     assert abs(gst["tri_tests"] - wst["tri_tests"]) <= 0.01 * wst["tri_tests"]
+
+
+def test_list_overflow_falls_back_to_the_host_builder(gpu, monkeypatch, capfd):
+    """An internal limit of the device builder (task / small-subtree list overflow) is not the caller's problem: append_blas() reports it on
+    stderr and builds that BLAS on the host.  NRAYS_DEBUG_BUILD_CAPS shrinks the lists to 1 / n of their capacity so that the path runs; the
+    frame must equal both the host-built and the (unconstrained) device-built one."""
+    def make():
+        pts, idx = _soup(30000, 5, 2.0, 0.05)
+        pts = pts.astype(np.float32)
+        mat = nr.PhongMaterial((0.1, 0.1, 0.1), (1, 1, 1), (1, 1, 1), None, None, 50.0)
+        node = nr.SceneNode(mat, 0.0, 0.0, 1.0, 1.0, nr.Isometry3((0.0, 0.0, 0.0), (0.0, 0.0, 0.0)), nr.TriMesh(pts.astype(np.float64), idx, None))
+        return nr.Scene([node], [nr.Light((0.0, 3.0, -6.0), 0.0, 1, (1, 1, 1))], (1, 1, 1)), dict(eye=(0.0, 0.5, -6.0), at=(0.0, 0.0, 0.0), fovy=40.0)
+    monkeypatch.setenv("NRAYS_GPU_BUILD", "0")
+    host, hst = _frame(make, 200, 120)
+    monkeypatch.delenv("NRAYS_GPU_BUILD")
+    monkeypatch.setenv("NRAYS_GPU_BUILD_MIN", "1")
+    dev, dst = _frame(make, 200, 120)
+    capfd.readouterr()
+    monkeypatch.setenv("NRAYS_DEBUG_BUILD_CAPS", "100000")
+    fb, fst = _frame(make, 200, 120)
+    msg = capfd.readouterr().err
+    assert "overflow" in msg and "building this BLAS on the host" in msg, msg
+    assert np.array_equal(fb, host) and np.array_equal(fb, dev)
+    for k in ("rays_primary", "rays_shadow", "hit_records", "node_tests"):
+        assert fst[k] == hst[k] == dst[k], (k, fst[k], hst[k], dst[k])
+
+
+def test_device_built_random_scenes_against_the_oracle(gpu, monkeypatch):
+    """50 random scenes of tools/fuzz_parity.py (mixed shapes + meshes, triangle soups with ties / duplicates / merged groups, hair) with
+    EVERY mesh BLAS built on the device, two frames each (the second runs from the cost order), against the CPU oracle: 1e-4 per channel and
+    equal ray classes — the sweep of profiles/r04_fuzz_device_build.log as a test."""
+    import torch
+    import oracle
+    from tools import fuzz_parity as fz
+    monkeypatch.setenv("NRAYS_GPU_BUILD_MIN", "1")
+    lib = abi.load_hip_lib()
+    worst = 0.0
+    for seed in range(31000, 31050):
+        sc, cam, rng = fz.random_hair_scene(seed) if seed % 3 == 2 else (fz.random_mesh_scene(seed) if seed % 2 else fz.random_scene(seed))
+        w, h = int(rng.integers(40, 120)), int(rng.integers(30, 90))
+        spp = int(rng.choice([1, 1, 2]))
+        p, _ = su.camera_params(cam, w, h, spp=spp, window=float(rng.choice([0.0, 1.0])) if spp > 1 else 0.0, seed=int(seed), max_depth=int(rng.choice([3, 5])))
+        ref, ost = oracle.render(sc.descriptor, p, 16)
+        out = torch.empty((h, w, 3), dtype=torch.float32, device="cuda")
+        for rep in range(2):
+            abi.check(lib.nrays_render_device(sc.device_handle(), C.byref(p), C.c_void_p(out.data_ptr()), None))
+            st = nr.get_stats(sc)
+            err = float(np.abs(out.cpu().numpy() - ref).max())
+            worst = max(worst, err)
+            assert err <= 1e-4, (seed, rep, err)
+            for k in ("rays_primary", "rays_reflection", "rays_refraction", "rays_shadow"):
+                assert getattr(st, k) == getattr(ost, k), (seed, rep, k, getattr(st, k), getattr(ost, k))
+    assert worst <= 1e-4
