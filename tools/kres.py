@@ -16,7 +16,7 @@ import __graft_entry__ as g  # noqa: E402
 
 
 def main():
-    out = os.path.join(ROOT, "nrays_amd", "lib", "ab", "kres.so")  # never the product library: a failed link must not clobber it
+    out = os.path.join(ROOT, "nrays_amd", "lib", "v", "kres.so")  # never the product library: a failed link must not clobber it
     extra, isa = [], False
     args = sys.argv[1:]
     while args:
