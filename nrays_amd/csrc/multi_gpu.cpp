@@ -100,6 +100,7 @@ struct NraysSceneSet {
     size_t tile_floats = 0, gathered_floats = 0;
     uint32_t width = 0, height = 0;
     uint64_t step = 0;
+    bool direct = false; // NRAYS_MULTI_DIRECT=1: every band travels straight into its rows of the frame (no gather buffer, no k_untile pass)
     bool has_root() const { return !local.empty() && local[0].index == 0; }
 };
 
@@ -217,6 +218,7 @@ int nrays_scene_set_create(const NraysSceneDesc* desc, NraysComm* comm, NraysSce
     *out_set = nullptr;
     NraysSceneSet* s = new NraysSceneSet();
     s->comm = comm;
+    if (const char* e = getenv("NRAYS_MULTI_DIRECT")) s->direct = atoi(e) != 0;
     DeviceGuard guard;
     auto bail = [&](int rc) { nrays_scene_set_destroy(s); return rc; };
     const uint32_t first = comm->ranked ? comm->rank : 0u, count = comm->ranked ? 1u : comm->owners;
@@ -316,7 +318,71 @@ int nrays_render_multi_device(NraysSceneSet* s, const NraysRenderParams* params,
         MG_HIP(hipEventRecord(o.rendered[slot], o.render_stream));
         MG_HIP(hipStreamWaitEvent(o.comm_stream, o.rendered[slot], 0));
     }
-    if (owners > 1) {
+    if (owners > 1 && s->direct) {
+        // 2'. the exchange WITHOUT the gather buffer: local band lb of owner o IS rows (lb * owners + o) * 16 ... of the frame, contiguous on both
+        // sides, so it can land where it belongs — same-device owners with one strided 2-D copy each, the others with one ncclSend / ncclRecv
+        // per band in ONE group (RCCL fuses the operations of a peer) — and there is no un-permute pass.  A/B against the gather form:
+        // profiles/r05_multi_direct_ab.log.
+        const uint32_t W = params->width, H = params->height;
+        const size_t band_floats = (size_t)kBandRows * W * 3;
+        auto bands_of = [&](uint32_t o) -> uint32_t { const uint32_t nb = (H + kBandRows - 1) / kBandRows; return nb > o ? (nb - o + owners - 1) / owners : 0u; };
+        auto rows_of = [&](uint32_t o, uint32_t lb) -> uint32_t { const uint32_t r0 = (lb * owners + o) * kBandRows; return r0 >= H ? 0u : (H - r0 < kBandRows ? H - r0 : kBandRows); };
+        const int root_dev = c->ranked ? -1 : c->devices[0];
+        NraysSceneSet::Owner* root = s->has_root() ? &s->local[0] : nullptr;
+        if (s->t_ready) { MG_HIP(hipSetDevice(s->local[0].device)); MG_HIP(hipEventRecord(s->t_exch0[tslot], s->local[0].comm_stream)); s->t_has_exchange[tslot] = true; }
+        bool any_rccl = c->ranked;
+        for (auto& o : s->local) { // owners on owner 0's device (owner 0 itself among them): copies on its communication stream
+            if (c->ranked ? o.index != 0 : o.device != root_dev) { any_rccl = true; continue; }
+            if (!root) continue;
+            MG_HIP(hipSetDevice(root->device));
+            MG_HIP(hipStreamWaitEvent(root->comm_stream, o.rendered[slot], 0));
+            const uint32_t nb = bands_of(o.index);
+            const uint32_t full = nb && rows_of(o.index, nb - 1) == kBandRows ? nb : (nb ? nb - 1 : 0u);
+            float* dst0 = out_rgb_device + (size_t)o.index * band_floats;
+            if (full) MG_HIP(hipMemcpy2DAsync(dst0, (size_t)owners * band_floats * sizeof(float), o.tile[slot], band_floats * sizeof(float), band_floats * sizeof(float), full, hipMemcpyDeviceToDevice, root->comm_stream));
+            if (full < nb) MG_HIP(hipMemcpyAsync(dst0 + (size_t)full * owners * band_floats, o.tile[slot] + (size_t)full * band_floats, (size_t)rows_of(o.index, full) * W * 3 * sizeof(float), hipMemcpyDeviceToDevice, root->comm_stream));
+        }
+        if (any_rccl && !c->comms.empty()) {
+            MG_NCCL(ncclGroupStart());
+            int group_rc = NRAYS_OK; std::string group_msg;
+            auto hip_ok = [&](hipError_t e, const char* what) { if (e != hipSuccess && group_rc == NRAYS_OK) { group_rc = NRAYS_ERR_HIP; group_msg = std::string(what) + ": " + hipGetErrorString(e); } return e == hipSuccess; };
+            auto nccl_ok = [&](ncclResult_t r, const char* what) { if (r != ncclSuccess && group_rc == NRAYS_OK) { group_rc = NRAYS_ERR_RCCL; group_msg = std::string(what) + ": " + ncclGetErrorString(r); } return r == ncclSuccess; };
+            auto recv_bands = [&](uint32_t o, int peer, ncclComm_t comm) {
+                for (uint32_t lb = 0; lb < bands_of(o) && group_rc == NRAYS_OK; ++lb)
+                    nccl_ok(ncclRecv(out_rgb_device + ((size_t)lb * owners + o) * band_floats, (size_t)rows_of(o, lb) * W * 3, ncclFloat, peer, comm, root->comm_stream), "ncclRecv");
+            };
+            auto send_bands = [&](NraysSceneSet::Owner& o, int peer, ncclComm_t comm) {
+                for (uint32_t lb = 0; lb < bands_of(o.index) && group_rc == NRAYS_OK; ++lb)
+                    nccl_ok(ncclSend(o.tile[slot] + (size_t)lb * band_floats, (size_t)rows_of(o.index, lb) * W * 3, ncclFloat, peer, comm, o.comm_stream), "ncclSend");
+            };
+            if (c->ranked) {
+                if (c->rank == 0) { for (uint32_t r = 1; r < owners && group_rc == NRAYS_OK; ++r) recv_bands(r, (int)r, c->comms[0]); }
+                else send_bands(s->local[0], 0, c->comms[0]);
+            } else {
+                const int root_ci = c->comm_index_of_device(root_dev);
+                for (auto& o : s->local) {
+                    if (o.index == 0 || o.device == root_dev) continue;
+                    if (group_rc != NRAYS_OK) break;
+                    const int ci = c->comm_index_of_device(o.device);
+                    if (!hip_ok(hipSetDevice(o.device), "hipSetDevice")) break;
+                    send_bands(o, root_ci, c->comms[ci]);
+                    if (!hip_ok(hipSetDevice(root_dev), "hipSetDevice")) break;
+                    recv_bands(o.index, ci, c->comms[root_ci]);
+                }
+            }
+            nccl_ok(ncclGroupEnd(), "ncclGroupEnd");
+            if (group_rc != NRAYS_OK) {
+                poison(c);
+                return nrays::set_last_error(group_rc, group_msg + " (exchange aborted; the communicator is no longer usable)");
+            }
+        }
+        for (auto& o : s->local) { // tile[slot] may be rendered into again once its copy / send is done
+            MG_HIP(hipSetDevice(o.device));
+            const bool on_root = root && (c->ranked ? o.index == 0 : o.device == root_dev);
+            MG_HIP(hipEventRecord(o.sent[slot], on_root ? root->comm_stream : o.comm_stream));
+        }
+        if (s->t_ready) { MG_HIP(hipSetDevice(s->local[0].device)); MG_HIP(hipEventRecord(s->t_exch1[tslot], s->local[0].comm_stream)); }
+    } else if (owners > 1) {
         // 2. the exchange: same-device owners copy, the others send / owner 0 receives (one grouped RCCL call)
         const int root_dev = c->ranked ? -1 : c->devices[0];
         NraysSceneSet::Owner* root = s->has_root() ? &s->local[0] : nullptr;

@@ -1284,7 +1284,16 @@ int nrays_scene_create(const NraysSceneDesc* desc, NraysScene** out_scene) {
     if (hipGetDevice(&sc->device) != hipSuccess) return bail(fail(NRAYS_ERR_HIP, "hipGetDevice failed"));
     std::string err;
     const auto t_create0 = std::chrono::steady_clock::now();
+    auto t_stage = t_create0;
+    const bool stage_times = getenv("NRAYS_BUILD_TIMES") != nullptr;
+    auto stage = [&](const char* what) { // NRAYS_BUILD_TIMES: where nrays_scene_create spends its time
+        if (!stage_times) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "  nrays_scene_create: %s %.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_stage).count());
+        t_stage = now;
+    };
     int rc = build_host_scene(desc, sc->host, err);
+    stage("build_host_scene (BLAS + TLAS builds)");
     if (rc != NRAYS_OK) return bail(fail(rc, err));
     HostScene& h = sc->host;
     const auto t_create1 = std::chrono::steady_clock::now();
@@ -1334,6 +1343,7 @@ int nrays_scene_create(const NraysSceneDesc* desc, NraysScene** out_scene) {
         if (h.shade_alpha_tex[i] >= 0) h.shade[i].alpha_tex.texels = trecs[h.shade_alpha_tex[i]].texels;
     }
     if ((rc = upload(sc, h.shade, &sc->d.shade)) != NRAYS_OK) return bail(rc);
+    stage("uploads (nodes, triangles, records, textures)");
     if (getenv("NRAYS_BUILD_TIMES") && h.tris.size() + h.dev_tris > 1000000)
         fprintf(stderr, "  nrays_scene_create: build_host_scene %.2f s, uploads %.2f s\n", std::chrono::duration<double>(t_create1 - t_create0).count(),
                 std::chrono::duration<double>(std::chrono::steady_clock::now() - t_create1).count());
@@ -1443,6 +1453,7 @@ int nrays_scene_create(const NraysSceneDesc* desc, NraysScene** out_scene) {
             return bail(fail(NRAYS_ERR_HIP, "counter memset failed"));
     }
     sc->d_counts = sc->d_counts_set[0]; sc->d_counters = sc->d_counters_set[0];
+    stage("records, switches, counters");
     if (hipMalloc((void**)&sc->d_counters_primary, sizeof(DeviceCounters)) != hipSuccess)
         return bail(fail(NRAYS_ERR_OOM, "counter allocation failed"));
     if (hipStreamCreate(&sc->own_stream) != hipSuccess) return bail(fail(NRAYS_ERR_HIP, "stream creation failed"));
@@ -1450,6 +1461,7 @@ int nrays_scene_create(const NraysSceneDesc* desc, NraysScene** out_scene) {
         if (hipEventCreate(&sc->ev_begin[k]) != hipSuccess || hipEventCreate(&sc->ev_pbegin[k]) != hipSuccess ||
             hipEventCreate(&sc->ev_pend[k]) != hipSuccess || hipEventCreate(&sc->ev_end[k]) != hipSuccess)
             return bail(fail(NRAYS_ERR_HIP, "event creation failed"));
+    stage("stream + event ring");
     {   // What a first frame would allocate, sized for frames up to 4K (larger ones re-allocate as before): the reference's caller
         // renders a camera ONCE (loader3d.rs:67-93), so the first frame of a handle is the one that counts for it.
         const char* e = getenv("NRAYS_PREALLOC"); // =0: allocate on the first frame (A/B switch)
@@ -1464,6 +1476,7 @@ int nrays_scene_create(const NraysSceneDesc* desc, NraysScene** out_scene) {
             if (sc->spill_entries && hipMalloc((void**)&sc->d_spill, (size_t)kMaxGrid * kBlock * sc->spill_entries * sizeof(uint32_t)) != hipSuccess) { sc->d_spill = nullptr; (void)hipGetLastError(); }
         }
     }
+    stage("first-frame buffers");
     *out_scene = sc;
     return NRAYS_OK;
 }
