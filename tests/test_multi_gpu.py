@@ -24,8 +24,13 @@ def _single(scene, params):
     return out, nr.get_stats(scene)
 
 
+@pytest.mark.parametrize("direct", [False, True])
 @pytest.mark.parametrize("owners", [1, 2, 3, 8])
-def test_render_multi_is_bit_identical_for_any_number_of_owners(gpu, owners):
+def test_render_multi_is_bit_identical_for_any_number_of_owners(gpu, owners, direct, monkeypatch):
+    """direct: NRAYS_MULTI_DIRECT=1 (read when the scene set is created) — every band goes straight into its rows of the frame (one strided
+    2-D copy per same-device owner, the ragged last band apart), no gather buffer and no k_untile pass."""
+    if direct:
+        monkeypatch.setenv("NRAYS_MULTI_DIRECT", "1")
     lib = abi.load_hip_lib()
     sc, cam = su.mesh_scene()
     p, _ = su.camera_params(cam, 200, 117)  # 8 bands of 16 rows, the last one ragged
