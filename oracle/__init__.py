@@ -12,7 +12,7 @@ import numpy as np
 from nrays_amd import abi
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_DIR, "_build", "libnrays_oracle.so")
+LIB_PATH = os.environ.get("NRAYS_ORACLE_LIB") or os.path.join(_DIR, "_build", "libnrays_oracle.so")  # (NRAYS_ORACLE_LIB: the sanitizer build, tests/test_oracle_sanitizers.py)
 _lib = None
 
 
