@@ -1035,6 +1035,10 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
     const bool timed = instrumented || (sc->frames_total % sc->event_stride) == 0;
     sc->frames_total++;
     const int slot = (int)(sc->frames_recorded % NraysScene::kRing);
+    if (timed && !sc->ev_begin[slot])
+        if (hipEventCreate(&sc->ev_begin[slot]) != hipSuccess || hipEventCreate(&sc->ev_pbegin[slot]) != hipSuccess ||
+            hipEventCreate(&sc->ev_pend[slot]) != hipSuccess || hipEventCreate(&sc->ev_end[slot]) != hipSuccess)
+            return fail(NRAYS_ERR_HIP, "event creation failed");
     // events: [pbegin .. pend] brackets the first primary launch; the frame spans [pbegin .. end], and
     // `end` is only recorded separately when something follows the primary kernel
     // The staged ("wavefront") form of the trace loop (wavefront.hip) renders this frame instead of k_primary when the scene is eligible and
@@ -1318,16 +1322,28 @@ int nrays_scene_create(const NraysSceneDesc* desc, NraysScene** out_scene) {
         for (nrays::DeviceBlas& b : h.dev_blas) nrays::free_device_blas(b);
         h.dev_blas.clear();
     }
-    if ((rc = upload(sc, h.instances, &sc->d.instances)) != NRAYS_OK) return bail(rc);
-    if ((rc = upload(sc, h.shadow_instances, &sc->d.shadow_instances)) != NRAYS_OK) return bail(rc);
-    if ((rc = upload(sc, h.links, &sc->d.links)) != NRAYS_OK) return bail(rc);
-    if ((rc = upload(sc, h.shadow_links, &sc->d.shadow_links)) != NRAYS_OK) return bail(rc);
-
-    if ((rc = upload(sc, h.node_aabbs, &sc->d.node_aabbs)) != NRAYS_OK) return bail(rc);
-
-    if ((rc = upload(sc, h.lights, &sc->d.lights)) != NRAYS_OK) return bail(rc);
-    if ((rc = upload(sc, h.planes, &sc->d.planes)) != NRAYS_OK) return bail(rc);
-    if ((rc = upload(sc, h.shadow_planes, &sc->d.shadow_planes)) != NRAYS_OK) return bail(rc);
+    {   // the scene's small record arrays: ONE allocation and ONE copy (eight synchronous hipMalloc + hipMemcpy pairs before)
+        struct Part { const void* src; size_t bytes; const void** out; size_t at; };
+        std::vector<Part> parts;
+        size_t total = 0;
+        auto add = [&](const auto& v, auto** out) {
+            *out = nullptr;
+            if (v.empty()) return;
+            total = (total + 255u) & ~(size_t)255u;
+            parts.push_back(Part{v.data(), v.size() * sizeof(v[0]), (const void**)out, total});
+            total += v.size() * sizeof(v[0]);
+        };
+        add(h.instances, &sc->d.instances); add(h.shadow_instances, &sc->d.shadow_instances); add(h.links, &sc->d.links); add(h.shadow_links, &sc->d.shadow_links);
+        add(h.node_aabbs, &sc->d.node_aabbs); add(h.lights, &sc->d.lights); add(h.planes, &sc->d.planes); add(h.shadow_planes, &sc->d.shadow_planes);
+        if (total) {
+            void* blk = nullptr;
+            if (hipMalloc(&blk, total) != hipSuccess) return bail(fail(NRAYS_ERR_OOM, "record allocation failed"));
+            sc->allocs.push_back(blk); sc->scene_bytes += total;
+            std::vector<char> stage(total);
+            for (const Part& pt : parts) { std::memcpy(stage.data() + pt.at, pt.src, pt.bytes); *pt.out = (const char*)blk + pt.at; }
+            if (hipMemcpy(blk, stage.data(), total, hipMemcpyHostToDevice) != hipSuccess) return bail(fail(NRAYS_ERR_HIP, "record upload failed"));
+        }
+    }
     std::vector<TextureRec> trecs;
     for (HostTexture& t : h.textures) {
         void* p = nullptr;
@@ -1457,10 +1473,7 @@ int nrays_scene_create(const NraysSceneDesc* desc, NraysScene** out_scene) {
     if (hipMalloc((void**)&sc->d_counters_primary, sizeof(DeviceCounters)) != hipSuccess)
         return bail(fail(NRAYS_ERR_OOM, "counter allocation failed"));
     if (hipStreamCreate(&sc->own_stream) != hipSuccess) return bail(fail(NRAYS_ERR_HIP, "stream creation failed"));
-    for (int k = 0; k < NraysScene::kRing; ++k)
-        if (hipEventCreate(&sc->ev_begin[k]) != hipSuccess || hipEventCreate(&sc->ev_pbegin[k]) != hipSuccess ||
-            hipEventCreate(&sc->ev_pend[k]) != hipSuccess || hipEventCreate(&sc->ev_end[k]) != hipSuccess)
-            return bail(fail(NRAYS_ERR_HIP, "event creation failed"));
+    // (the ring's timing events are created by the first frame that records into a slot: 1 024 hipEventCreate cost 0.6 ms of every scene creation)
     stage("stream + event ring");
     {   // What a first frame would allocate, sized for frames up to 4K (larger ones re-allocate as before): the reference's caller
         // renders a camera ONCE (loader3d.rs:67-93), so the first frame of a handle is the one that counts for it.
