@@ -8,4 +8,4 @@ from tools import standins
 for name, make in (("hairball", standins.hairball_scene), ("hairball again", standins.hairball_scene), ("sponza", standins.sponza_scene)):
     t = time.perf_counter(); sc, cam = make(); t1 = time.perf_counter()
     h = sc.device_handle(); torch.cuda.synchronize(); t2 = time.perf_counter()
-    print("%s: python scene %.2f s, nrays_scene_create %.2f s" % (name, t1 - t, t2 - t1), flush=True)
+    print("%s: python scene %.2f s, nrays_scene_create %.4f s" % (name, t1 - t, t2 - t1), flush=True)
