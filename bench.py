@@ -110,11 +110,13 @@ def roofline_block(pk, tst, W, owned_rows, scene_bytes, pmc, pmc_source, tile_co
          "algorithmic_bytes_per_launch": int(record_bytes), "kernel_ms": round(t * 1e3, 5), "kernel_ms_events": round(tst.kernel_ms_primary, 5),
          "frame_gpu_ms": round(tst.kernel_ms_total, 5), "launches_timed": int(tst.frames_timed),
          "compulsory_bytes": int(scene_bytes + fb),
-         "units_per_launch": {"rays": int(pk.total_rays()), "rays_traced": int(pk.rays_traced()), "node_tests": int(pk.node_tests), "tri_tests": int(pk.tri_tests),
+         "units_per_launch": {"rays": int(pk.total_rays()), "rays_traced": int(pk.rays_traced()) - int(tst.rays_shadow_elided),
+                              "rays_shadow_counted_not_traced": int(tst.rays_shadow_elided), "node_tests": int(pk.node_tests), "tri_tests": int(pk.tri_tests),
                               "prim_tests": int(pk.prim_tests), "hit_records": int(pk.hit_records), "tex_samples": int(pk.tex_samples)},
          "note": "frac = max over real ceilings (hbm: PMC DRAM bytes, l2: TCC requests x 128 B, valu: VALU-issue cycles), each <= 1; "
-                 "contract_* = SURVEY 8d algorithmic record bytes of the tests actually run / kernel time / HBM peak (a rate of useful bytes "
-                 "served from caches and SGPR broadcasts, may exceed 1, not a utilisation); the kernels are latency-bound (wave_wait_frac): "
+                 "contract_* = SURVEY 8d algorithmic record bytes (the tests of the instrumented frame, which traces every ray the reference "
+                 "traces; plain frames leave out the shadow rays of hits without a term of their own: rays_shadow_counted_not_traced) / kernel time / "
+                 "HBM peak (a rate of useful bytes served from caches and SGPR broadcasts, may exceed 1, not a utilisation); the kernels are latency-bound (wave_wait_frac): "
                  "`limiter` names what the schedule waits for"}
     if tile_costs is not None and t > 0 and tile_costs.tiles:
         # shader cycles -> seconds at the guide's 2.4 GHz maximum (the clock under load is lower: the fractions are lower bounds)
@@ -332,6 +334,9 @@ def single_gpu_measure(name, W, H, steps, warmup, args, pmc=True, moving=True):
     dt = time.perf_counter() - t0
     tst = nr.get_stats(scene)
     plain = st  # the instrumented frame's counters: rays_primary_traced (what reached a BVT query) is only counted there
+    # shadow rays of hits that contribute nothing of their own (fully transparent points, perfect mirrors): counted in rays_shadow — the reference traces
+    # them — but not traced by the plain (timed) frames; they are not part of the traced rate
+    elided = int(tst.rays_shadow_elided)
     res = {"workload": desc % (W, H), "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 5), "ray_per_pixel": int(cam.get("spp", 1)),
            "value": round(st.total_rays() * steps / dt / 1e6, 3), "unit": "Mrays/s",
            "steady_state": "resting camera: %d untimed settle frames before --warmup (per-camera cost order decided); kernel_ms from HIP events on every 4th frame" % settle,
@@ -339,8 +344,9 @@ def single_gpu_measure(name, W, H, steps, warmup, args, pmc=True, moving=True):
                               "refraction": int(st.rays_refraction), "shadow": int(st.rays_shadow)},
            # rays that went through a BVT query: the wave tiles the scene's screen bounds or the root test decide write the
            # background without one (same pixels; the reference would have queried) — the rate on them is the honest traversal rate
-           "rays_traced_per_frame": int(plain.rays_traced()),
-           "value_traced": round(plain.rays_traced() * steps / dt / 1e6, 3),
+           "rays_traced_per_frame": int(plain.rays_traced()) - elided,
+           "rays_shadow_counted_not_traced_per_frame": elided,
+           "value_traced": round((plain.rays_traced() - elided) * steps / dt / 1e6, 3),
            "scene_build_s": round(scene_build_s, 4),
            "scene_build_note": "nrays_scene_create as the caller sees it; BLASes of >= 2 000 triangles are built on the GPU (nrays_amd/csrc/bvh_device.hip), smaller ones and the TLASes on the host",
            "cold_frame_ms": round(first[0], 4), "second_frame_ms": round(first[1], 4), "third_frame_ms": round(first[2], 4),

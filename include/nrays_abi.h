@@ -29,8 +29,8 @@
 extern "C" {
 #endif
 
-/* Bumped whenever the exported surface grows or a struct changes: 3 = + nrays_debug_blas_build / NraysBlasDump, nrays_multi_get_timings / NraysMultiTimings (round 4). */
-#define NRAYS_ABI_VERSION 3
+/* Bumped whenever the exported surface grows or a struct changes: 3 = + nrays_debug_blas_build / NraysBlasDump, nrays_multi_get_timings / NraysMultiTimings (round 4); 4 = NraysStats::rays_shadow_elided (round 5). */
+#define NRAYS_ABI_VERSION 4
 
 typedef enum NraysStatus {
     NRAYS_OK = 0,
@@ -189,6 +189,9 @@ typedef struct NraysStats {
     uint64_t rays_primary_traced; /* instrumented renders only: primary rays that went through a BVT query: rays_primary minus the ones whose wave tile was
                                      decided without one (outside the scene's screen bounds, or no ray of the tile passes the
                                      root of the BVT) — the pixels are the same, the reference would have queried for them */
+    uint64_t rays_shadow_elided;  /* part of rays_shadow: shadow rays the reference traces from hits that contribute nothing of their own to the pixel (a
+                                     fully transparent point: opacity-map texel 0 or node alpha 0; a perfect mirror: scene.rs:179-190) — counted, so that
+                                     rays_shadow stays the reference's number, but not traced by plain renders of alpha-mapped mesh scenes (instrumented renders trace them: 0) */
 } NraysStats;
 
 /* Threading contract of a scene handle: the library is re-entrant on DISTINCT handles (any threads, any streams).

@@ -4,7 +4,7 @@
 
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const NRAYS_ABI_VERSION: u32 = 3; // include/nrays_abi.h; GpuScene::new refuses a library built from another header
+pub const NRAYS_ABI_VERSION: u32 = 4; // include/nrays_abi.h; GpuScene::new refuses a library built from another header
 pub const NRAYS_OK: c_int = 0;
 pub const NRAYS_ERR_BAD_ARG: c_int = -1;
 pub const NRAYS_ERR_HIP: c_int = -2;
@@ -156,6 +156,7 @@ pub struct NraysStats {
     pub frames_timed: u32,
     pub reserved: u32,
     pub rays_primary_traced: u64,
+    pub rays_shadow_elided: u64,
 }
 
 #[repr(C)]

@@ -6,7 +6,7 @@ and types must match include/nrays_abi.h exactly (tests/test_abi.py checks sizes
 import ctypes as C
 import os
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # NraysStatus
 OK = 0
@@ -76,11 +76,11 @@ class NraysStats(C.Structure):
                 ("prim_tests", C.c_uint64), ("hit_records", C.c_uint64), ("tex_samples", C.c_uint64),
                 ("generations", C.c_uint32), ("instrumented", C.c_uint32), ("kernel_ms_primary", C.c_double),
                 ("kernel_ms_total", C.c_double), ("frames_timed", C.c_uint32), ("reserved", C.c_uint32),
-                ("rays_primary_traced", C.c_uint64)]
+                ("rays_primary_traced", C.c_uint64), ("rays_shadow_elided", C.c_uint64)]
 
     def rays_traced(self):
         """Rays that went through a BVT query (total_rays() counts every primary ray the reference would trace)."""
-        return self.rays_primary_traced + self.rays_reflection + self.rays_refraction + self.rays_shadow
+        return self.rays_primary_traced + self.rays_reflection + self.rays_refraction + self.rays_shadow - self.rays_shadow_elided
 
     def total_rays(self):
         return self.rays_primary + self.rays_reflection + self.rays_refraction + self.rays_shadow

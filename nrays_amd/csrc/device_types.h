@@ -140,7 +140,7 @@ struct DeviceCounters {
     unsigned int overflow;  // set when a continuation queue ran out of capacity
     unsigned int max_depth; // deepest trace depth reached (= number of continuation generations)
     unsigned int max_chain_nodes; // instrumented: most AABB tests spent on one pixel's chain
-    unsigned int pad;
+    unsigned int shadow_elided; // shadow rays counted in rays_shadow but not traced: hits on fully transparent / perfectly mirroring points contribute nothing of their own (trace_device.h: shade_hit)
     unsigned long long dbg2[8];   // tuning builds (NR_PHASE_TIMING): wave cycles outside the queries — dequeue wait, raygen + root test, hit reconstruction + gates, shadow-ray set-up, material, weights + continuation, pixel write
     unsigned long long dbg[8];    // tuning builds (NR_PHASE_TIMING): wave / lane iteration counts of the node loops and triangle leaves, cycles per query class, wave-uniform node iterations
 };

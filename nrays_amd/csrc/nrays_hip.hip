@@ -80,11 +80,11 @@ __device__ __forceinline__ uint32_t issue_grab(uint32_t* work_counters, uint32_t
 
 __device__ __forceinline__ void flush_counters(DeviceCounters* ctr, const Cnt& c, bool stats) {
     // wave-level reduction, then one atomic per wave and class
-    unsigned sh = c.shadow, rl = c.refl, rf = c.refr, md = c.max_depth, mc = c.max_chain_nodes;
+    unsigned sh = c.shadow, rl = c.refl, rf = c.refr, md = c.max_depth, mc = c.max_chain_nodes, el = c.elided;
     unsigned nd = c.node, tr = c.tri, pr = c.prim, ht = c.hit, tx = c.tex, tc = c.traced;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
-        sh += __shfl_down(sh, off); rl += __shfl_down(rl, off); rf += __shfl_down(rf, off);
+        sh += __shfl_down(sh, off); rl += __shfl_down(rl, off); rf += __shfl_down(rf, off); el += __shfl_down(el, off);
         unsigned om = __shfl_down(md, off); md = om > md ? om : md;
         if (stats) { unsigned oc = __shfl_down(mc, off); mc = oc > mc ? oc : mc; }
         if (stats) { nd += __shfl_down(nd, off); tr += __shfl_down(tr, off); pr += __shfl_down(pr, off); ht += __shfl_down(ht, off); tx += __shfl_down(tx, off); tc += __shfl_down(tc, off); }
@@ -118,6 +118,7 @@ __device__ __forceinline__ void flush_counters(DeviceCounters* ctr, const Cnt& c
 #endif
     if (__lane_id() == 0) {
         if (sh) atomicAdd(&ctr->rays_shadow, (unsigned long long)sh);
+        if (el) atomicAdd(&ctr->shadow_elided, el);
         if (rl) atomicAdd(&ctr->rays_reflection, (unsigned long long)rl);
         if (rf) atomicAdd(&ctr->rays_refraction, (unsigned long long)rf);
         if (md) atomicMax(&ctr->max_depth, md);
@@ -195,7 +196,7 @@ __global__ void __launch_bounds__(kBlock, OCC ? NR_OCC3_AS : waves_per_simd(FEAT
     st.lds0 = Stack::addr((lds_u32*)lds_stack);
     st.park = (lds_u32*)(lds_park + threadIdx.x);
     st.init();
-    Cnt cnt; cnt.node = cnt.tri = cnt.prim = cnt.hit = cnt.tex = cnt.shadow = cnt.refl = cnt.refr = cnt.max_depth = cnt.max_chain_nodes = cnt.traced = 0;
+    Cnt cnt; cnt.node = cnt.tri = cnt.prim = cnt.hit = cnt.tex = cnt.shadow = cnt.refl = cnt.refr = cnt.max_depth = cnt.max_chain_nodes = cnt.traced = cnt.elided = 0;
 #ifdef NR_PHASE_TIMING
     cnt.cyc_node = cnt.cyc_leaf = cnt.cyc_other = cnt.cyc_tri = 0; cnt.wv_node = cnt.ln_node = cnt.wv_tri = cnt.ln_tri = 0; cnt.cyc_closest0 = cnt.cyc_closestN = cnt.cyc_shadow = 0; cnt.wv_uni = 0; cnt.inq_node = cnt.inq_tri = 0; for (int k_ = 0; k_ < 8; ++k_) cnt.cyc_x[k_] = 0;
     unsigned long long twave = __builtin_readcyclecounter();
@@ -488,7 +489,7 @@ __global__ void __launch_bounds__(kBlock, NRAYS_WAVES_PER_SIMD) k_bounce(DScene 
     st.lds0 = Stack::addr((lds_u32*)lds_stack);
     st.park = nullptr;
     st.init();
-    Cnt cnt; cnt.node = cnt.tri = cnt.prim = cnt.hit = cnt.tex = cnt.shadow = cnt.refl = cnt.refr = cnt.max_depth = cnt.max_chain_nodes = cnt.traced = 0;
+    Cnt cnt; cnt.node = cnt.tri = cnt.prim = cnt.hit = cnt.tex = cnt.shadow = cnt.refl = cnt.refr = cnt.max_depth = cnt.max_chain_nodes = cnt.traced = cnt.elided = 0;
 #ifdef NR_PHASE_TIMING
     cnt.cyc_node = cnt.cyc_leaf = cnt.cyc_other = cnt.cyc_tri = 0; cnt.wv_node = cnt.ln_node = cnt.wv_tri = cnt.ln_tri = 0; cnt.cyc_closest0 = cnt.cyc_closestN = cnt.cyc_shadow = 0; cnt.wv_uni = 0; cnt.inq_node = cnt.inq_tri = 0; for (int k_ = 0; k_ < 8; ++k_) cnt.cyc_x[k_] = 0;
 #endif
@@ -529,7 +530,7 @@ __global__ void __launch_bounds__(kBlock, NRAYS_WAVES_PER_SIMD) k_cast_batch(DSc
     st.lds0 = Stack::addr((lds_u32*)lds_stack);
     st.park = nullptr;
     st.init();
-    Cnt cnt; cnt.node = cnt.tri = cnt.prim = cnt.hit = cnt.tex = cnt.shadow = cnt.refl = cnt.refr = cnt.max_depth = cnt.max_chain_nodes = cnt.traced = 0;
+    Cnt cnt; cnt.node = cnt.tri = cnt.prim = cnt.hit = cnt.tex = cnt.shadow = cnt.refl = cnt.refr = cnt.max_depth = cnt.max_chain_nodes = cnt.traced = cnt.elided = 0;
 #ifdef NR_PHASE_TIMING
     cnt.cyc_node = cnt.cyc_leaf = cnt.cyc_other = cnt.cyc_tri = 0; cnt.wv_node = cnt.ln_node = cnt.wv_tri = cnt.ln_tri = 0; cnt.cyc_closest0 = cnt.cyc_closestN = cnt.cyc_shadow = 0; cnt.wv_uni = 0; cnt.inq_node = cnt.inq_tri = 0; for (int k_ = 0; k_ < 8; ++k_) cnt.cyc_x[k_] = 0;
 #endif
@@ -1555,6 +1556,7 @@ int nrays_get_stats(NraysScene* sc, NraysStats* out) {
     fill_counters(out, c);
     out->generations = c.max_depth; out->instrumented = sc->last_instrumented ? 1u : 0u;
     out->reserved = c.max_chain_nodes; // instrumented renders: most AABB tests spent on one pixel's whole chain
+    out->rays_shadow_elided = c.shadow_elided;
     // average the event timings of the frames recorded since the previous call (at most kRing)
     uint64_t first = sc->frames_reported;
     if (sc->frames_recorded - first > (uint64_t)NraysScene::kRing) first = sc->frames_recorded - NraysScene::kRing;

@@ -52,6 +52,9 @@ constexpr int32_t kParked = (int32_t)0x80000002;   // a lane that yielded its no
 #ifndef NR_NODE_QUORUM_DEN
 #define NR_NODE_QUORUM_DEN 3 // traverse(): node phases inside a hair-like mesh end below 1 / DEN of the query's lanes (0 = off)
 #endif
+#ifndef NR_ELIDE_TRANSPARENT
+#define NR_ELIDE_TRANSPARENT 1 // hits on fully transparent points skip their shadow rays and Phong (shade_hit())
+#endif
 #ifndef NR_SCALAR_NODES
 #define NR_SCALAR_NODES 1 // wave-uniform node visits fetch the node with scalar loads (traverse())
 #endif
@@ -113,6 +116,7 @@ struct Cnt {
     unsigned max_depth;                     // deepest trace depth reached by this lane
     unsigned max_chain_nodes;               // instrumented: most AABB tests in one pixel's chain
     unsigned traced;                        // instrumented: primary rays that entered the trace loop
+    unsigned elided;                        // shadow rays counted but not traced (shade_hit: hits that contribute nothing of their own)
 #ifdef NR_PHASE_TIMING
     unsigned cyc_node, cyc_leaf, cyc_other, cyc_tri; // per-wave cycles (valid in lane 0); cyc_tri is part of cyc_leaf
     unsigned wv_node, ln_node, wv_tri, ln_tri;       // iterations of the node loop / triangle loop: per wave (counted by the leading active lane) and per lane
@@ -1123,12 +1127,13 @@ NR_DEV bool shadow_query(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, 
 // `res = res + acc_l / n_l` light after light (phong_material.rs:106-147): the pixel is bit-identical to the one-lane loop.
 template <bool STATS, int FEAT>
 NR_MAT_ATTR f4 material_compute(const DScene& S, Stack& st, const ShadeRec& m, RayState& ray, d3& point, Isect& in, Cnt& cnt,
-                                bool pre, bool pre_lit, f3 pre_filter, uint32_t lsl = 0u) {
+                                bool pre, bool pre_lit, f3 pre_filter, uint32_t lsl = 0u, float alpha_in = -1.0f) {
     if (((m.flags >> 8) & 0xffu) != NRAYS_MAT_PHONG) return material_ambiant<STATS>(m, in, cnt);
     f4 tex; tex.x = tex.y = tex.z = tex.w = 1.0f;
     float alpha = 1.0f;
     if (in.has_uv && m.tex.texels) tex = tex_sample<STATS>(m.tex, in.u, in.v, cnt);
-    if (in.has_uv && m.alpha_tex.texels) alpha = tex_sample<STATS>(m.alpha_tex, in.u, in.v, cnt).w;
+    if (alpha_in >= 0.0f) alpha = alpha_in; // (shade_hit() sampled the opacity map already)
+    else if (in.has_uv && m.alpha_tex.texels) alpha = tex_sample<STATS>(m.alpha_tex, in.u, in.v, cnt).w;
     f3 res = F3(m.ka[0] * tex.x, m.ka[1] * tex.y, m.ka[2] * tex.z);
     d3 normal = in.n;
     // one light: the sum over its samples (light.rs:57-63 + phong_material.rs:108-146)
@@ -1290,11 +1295,39 @@ NR_DEV f3 shade_hit(const DScene& S, Stack& st, RayState& ray, uint32_t depth, u
         gated = true;
     }
     NR_TIC(tsh);
+    // A hit on a FULLY TRANSPARENT point (opacity-map texel 0, or node alpha 0: the holes of alpha-tested foliage, lace, chains) — or on a perfect mirror — contributes
+    // obj.rgb * (weight * 0 * (1 - mix)) = 0 to its pixel whatever its shading is (scene.rs:179-190) — the reference still traces its shadow rays and
+    // evaluates Phong.  Here the opacity is sampled first and such a hit goes straight to its refraction ray: the pixel is bit-identical (x + 0 = x;
+    // colours are finite), the shadow rays are COUNTED as the reference traces them (DeviceCounters::rays_shadow keeps the oracle's value) but not
+    // traced.  Not in the instrumented kernel, whose test / sample counts stay the reference algorithm's.  Sponza stand-in: half of the
+    // alpha-mapped hits, all of them on the frame's longest chains (profiles/r05_transparent_hit_elision_ab.log).  Only in the kernels of mesh scenes
+    // that hold a transparent node (kFeatMesh + kFeatAlphaShadow): in the opaque-mesh kernels the test alone cost 1 % of the hairball frames and in the
+    // analytic ones 1.5 % of the primitives frame (same log); a perfect mirror in such a scene is shaded as the reference shades it.
+    float alpha_known = -1.0f;
+    bool elide = false;
+    if (!STATS && NR_ELIDE_TRANSPARENT && (FEAT & kFeatAlphaShadow) && (FEAT & kFeatMesh)) {
+        const ShadeRec& sm = S.shade[node_id];
+        if (((sm.flags >> 8) & 0xffu) == NRAYS_MAT_PHONG) {
+            const bool mirror = sm.refl_mix == 1.0f; // (the same for a perfect mirror: its own term is obj.rgb * (weight * alpha * (1 - 1)))
+            if ((is.has_uv && sm.alpha_tex.texels) || sm.alpha == 0.0f || mirror) {
+                alpha_known = (is.has_uv && sm.alpha_tex.texels) ? tex_sample<STATS>(sm.alpha_tex, is.u, is.v, cnt).w : 1.0f;
+                elide = mirror || alpha_known * sm.alpha == 0.0f;
+            }
+        }
+    }
+    if (elide) {
+        if (count_me) { // the shadow rays the reference traces from this hit: one per light sample (light.rs:57-63)
+            unsigned n = 0u;
+            if (!(FEAT & kFeatMultiSample)) n = (S.num_lights == 1 && S.lights[0].racsample == 1u) ? 1u : 0u;
+            else for (uint32_t li = 0; li < S.num_lights; ++li) n += S.lights[li].racsample * S.lights[li].racsample;
+            cnt.shadow += n; cnt.elided += n;
+        }
+    }
     // Single-sample lighting (one point light, or one area light with racsample 1): trace the shadow ray NOW,
     // while only the ray, the hit distance and the chain state are live, and hand the result to the Phong
     // evaluation below — the normal / uv / texture state then never has to survive a traversal.  Same ray,
     // same result as phong_material.rs:109-112; only the evaluation order differs.
-    if (!(FEAT & kFeatMultiSample) && S.num_lights == 1 && ((S.shade[node_id].flags >> 8) & 0xffu) == NRAYS_MAT_PHONG) {
+    if (!elide && !(FEAT & kFeatMultiSample) && S.num_lights == 1 && ((S.shade[node_id].flags >> 8) & 0xffu) == NRAYS_MAT_PHONG) {
         const LightRec& light = S.lights[0];
         if (light.racsample == 1u) {
             d3 pos = D3(light.pos[0], light.pos[1], light.pos[2]);
@@ -1330,7 +1363,9 @@ NR_DEV f3 shade_hit(const DScene& S, Stack& st, RayState& ray, uint32_t depth, u
     if (STATS) cnt.hit++;
     const ShadeRec& sn = S.shade[node_id];
     d3 pt = ray.o + ray.d * hit.t;
-    f4 obj = material_compute<STATS, FEAT>(S, st, sn, ray, pt, is, cnt, pre, pre_lit, pre_filter, lsl);
+    f4 obj;
+    if (elide) { obj.x = obj.y = obj.z = 0.0f; obj.w = alpha_known; }
+    else obj = material_compute<STATS, FEAT>(S, st, sn, ray, pt, is, cnt, pre, pre_lit, pre_filter, lsl, alpha_known);
     NR_TOC(cyc_x[4], tsh);
     bool may_recurse = depth < (uint32_t)kMaxGenerations && (max_depth == 0 || depth < max_depth);
     float mix = sn.refl_mix;

@@ -1,0 +1,59 @@
+"""Hits that contribute nothing of their own to the pixel — a fully transparent point (opacity-map texel 0, node alpha 0: the holes of alpha-tested
+foliage) or a perfect mirror (refl_mix 1): obj.rgb * (weight * alpha * (1 - mix)) = 0, scene.rs:179-190 — are not shaded by plain renders
+(trace_device.h: shade_hit): their shadow rays are COUNTED (NraysStats::rays_shadow stays the reference's number, rays_shadow_elided says how many
+were not traced) and the pixel must be the bit-identical one of the instrumented render, which traces and shades everything, and the oracle's."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+import nrays_amd as nr
+import oracle
+from nrays_amd import abi
+from tools import scenes_util as su
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(n_lights, light_radius=0.0, nsample=1):
+    """An alpha-mapped wall (holes: alpha 0), a node of alpha 0 behind it, a perfect mirror ball, a half mirror, a floor."""
+    wall = nr.PhongMaterial((0.1, 0.3, 0.1), (0.2, 0.9, 0.3), (1, 1, 1), su.checker_texture(32, 4), su.checker_texture(32, 6, alpha_holes=True), 60.0)
+    plain = nr.PhongMaterial((0.2, 0.2, 0.25), (0.7, 0.7, 0.8), (1, 1, 1), None, None, 80.0)
+    quad = su.f32_exact([[-2.5, -1.0, 0.0], [2.5, -1.0, 0.0], [2.5, 2.0, 0.0], [-2.5, 2.0, 0.0]])
+    quv = su.f32_exact([[0, 0], [2, 0], [2, 1], [0, 1]])
+    qidx = np.asarray([[0, 2, 1], [0, 3, 2]], dtype=np.uint32)
+    fl = su.f32_exact([[-8, -1.25, -8], [8, -1.25, -8], [8, -1.25, 8], [-8, -1.25, 8]])
+    nodes = [
+        nr.SceneNode(wall, 0.0, 0.0, 1.0, 1.1, nr.Isometry3((0.0, 0.0, -2.0), (0.0, math.radians(10.0), 0.0)), nr.TriMesh(quad, qidx, quv)),
+        nr.SceneNode(plain, 0.0, 0.0, 0.0, 1.0, nr.Isometry3((0.0, 0.0, -1.0)), nr.TriMesh(quad, qidx, None)),      # alpha 0: invisible, still refracts
+        nr.SceneNode(plain, 1.0, 0.3, 1.0, 1.0, nr.Isometry3((-1.6, 0.0, 1.5)), nr.Ball(0.9)),                          # perfect mirror
+        nr.SceneNode(plain, 0.5, 0.3, 1.0, 1.0, nr.Isometry3((1.6, 0.0, 1.5)), nr.Ball(0.9)),                           # half mirror: shaded
+        nr.SceneNode(su.default_material(), 0.0, 0.0, 1.0, 1.0, nr.Isometry3((0.0, 0.0, 0.0)), nr.TriMesh(fl, qidx, quv)),
+    ]
+    lights = [nr.Light((3.0, 6.0, -6.0), light_radius, nsample, (0.7, 0.7, 0.7)), nr.Light((-4.0, 5.0, -2.0), 0.0, 1, (0.5, 0.5, 0.6)),
+              nr.Light((0.0, 7.0, 3.0), 0.0, 1, (0.3, 0.3, 0.3))][:n_lights]
+    per_hit = sum(l.racsample ** 2 for l in lights)  # shadow rays of one shaded hit (light.rs:20, scene.rs:262-299)
+    return nr.Scene(nodes, lights, (0.6, 0.7, 0.9)), dict(eye=(0.3, 2.0, -9.0), at=(0.0, 0.2, 0.0), fovy=40.0), per_hit
+
+
+@pytest.mark.parametrize("n_lights,radius,nsample,spp", [(1, 0.0, 1, 1), (3, 0.0, 1, 1), (2, 0.3, 4, 2)])
+def test_hits_without_a_term_of_their_own_are_counted_not_traced(gpu, n_lights, radius, nsample, spp):
+    import torch
+    lib = abi.load_hip_lib()
+    sc, cam, per_hit = _scene(n_lights, radius, nsample)
+    p, _ = su.camera_params(cam, 208, 120, **(dict(spp=spp, window=1.0, seed=5) if spp > 1 else {}))
+    ref, ost = oracle.render(sc.descriptor, p, 8)
+    out = torch.empty((120, 208, 3), dtype=torch.float32, device="cuda")
+    frames, stats = [], []
+    for fn in (lib.nrays_render_device, lib.nrays_render_device, lib.nrays_render_device_instrumented):  # (second plain frame: cost-ordered lists, split tiles)
+        abi.check(fn(sc.device_handle(), C.byref(p), C.c_void_p(out.data_ptr()), None))
+        frames.append(out.cpu().numpy().copy()); stats.append(nr.get_stats(sc))
+    assert np.array_equal(frames[0], frames[2]) and np.array_equal(frames[1], frames[2])      # not shading them changes no bit
+    assert float(np.abs(frames[0] - ref).max()) <= 1e-4
+    for st in stats:
+        for k in ("rays_primary", "rays_reflection", "rays_refraction", "rays_shadow"):
+            assert getattr(st, k) == getattr(ost, k), (k, getattr(st, k), getattr(ost, k))   # the reference's counts, traced or not
+    assert stats[2].rays_shadow_elided == 0                                                    # the instrumented render traces everything
+    assert 0 < stats[0].rays_shadow_elided == stats[1].rays_shadow_elided < stats[0].rays_shadow
+    assert stats[0].rays_shadow_elided % per_hit == 0                                          # whole hits: one ray per light sample each
