@@ -115,7 +115,8 @@ def roofline_block(pk, tst, W, owned_rows, scene_bytes, pmc, pmc_source, tile_co
                               "prim_tests": int(pk.prim_tests), "hit_records": int(pk.hit_records), "tex_samples": int(pk.tex_samples)},
          "note": "frac = max over real ceilings (hbm: PMC DRAM bytes, l2: TCC requests x 128 B, valu: VALU-issue cycles), each <= 1; "
                  "contract_* = SURVEY 8d algorithmic record bytes (the tests of the instrumented frame, which traces every ray the reference "
-                 "traces; plain frames leave out the shadow rays of hits without a term of their own: rays_shadow_counted_not_traced) / kernel time / "
+                 "traces; plain frames leave out the shadow rays whose result is multiplied by exactly 0 — light samples behind the surface, hits "
+                 "without a term of their own: rays_shadow_counted_not_traced) / kernel time / "
                  "HBM peak (a rate of useful bytes served from caches and SGPR broadcasts, may exceed 1, not a utilisation); the kernels are latency-bound (wave_wait_frac): "
                  "`limiter` names what the schedule waits for"}
     if tile_costs is not None and t > 0 and tile_costs.tiles:
@@ -334,8 +335,8 @@ def single_gpu_measure(name, W, H, steps, warmup, args, pmc=True, moving=True):
     dt = time.perf_counter() - t0
     tst = nr.get_stats(scene)
     plain = st  # the instrumented frame's counters: rays_primary_traced (what reached a BVT query) is only counted there
-    # shadow rays of hits that contribute nothing of their own (fully transparent points, perfect mirrors): counted in rays_shadow — the reference traces
-    # them — but not traced by the plain (timed) frames; they are not part of the traced rate
+    # shadow rays whose result is multiplied by exactly 0 (light samples behind the surface; hits that contribute nothing of their own: fully transparent
+    # points, perfect mirrors): counted in rays_shadow — the reference traces them — but not traced by the plain (timed) frames; not part of the traced rate
     elided = int(tst.rays_shadow_elided)
     res = {"workload": desc % (W, H), "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 5), "ray_per_pixel": int(cam.get("spp", 1)),
            "value": round(st.total_rays() * steps / dt / 1e6, 3), "unit": "Mrays/s",

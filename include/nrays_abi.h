@@ -189,9 +189,11 @@ typedef struct NraysStats {
     uint64_t rays_primary_traced; /* instrumented renders only: primary rays that went through a BVT query: rays_primary minus the ones whose wave tile was
                                      decided without one (outside the scene's screen bounds, or no ray of the tile passes the
                                      root of the BVT) — the pixels are the same, the reference would have queried for them */
-    uint64_t rays_shadow_elided;  /* part of rays_shadow: shadow rays the reference traces from hits that contribute nothing of their own to the pixel (a
-                                     fully transparent point: opacity-map texel 0 or node alpha 0; a perfect mirror: scene.rs:179-190) — counted, so that
-                                     rays_shadow stays the reference's number, but not traced by plain renders of alpha-mapped mesh scenes (instrumented renders trace them: 0) */
+    uint64_t rays_shadow_elided;  /* part of rays_shadow: shadow rays the reference traces although their result is multiplied by exactly 0 — light samples
+                                     behind the surface (diffuse and specular coefficients both 0: phong_material.rs:109-141) and the samples of hits that
+                                     contribute nothing of their own to the pixel (a fully transparent point: opacity-map texel 0 or node alpha 0; a perfect
+                                     mirror: scene.rs:179-190).  Counted, so that rays_shadow stays the reference's number, but not traced by plain
+                                     renders; instrumented renders trace them: 0 */
 } NraysStats;
 
 /* Threading contract of a scene handle: the library is re-entrant on DISTINCT handles (any threads, any streams).

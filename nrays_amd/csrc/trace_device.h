@@ -52,6 +52,9 @@ constexpr int32_t kParked = (int32_t)0x80000002;   // a lane that yielded its no
 #ifndef NR_NODE_QUORUM_DEN
 #define NR_NODE_QUORUM_DEN 3 // traverse(): node phases inside a hair-like mesh end below 1 / DEN of the query's lanes (0 = off)
 #endif
+#ifndef NR_ELIDE_DARK
+#define NR_ELIDE_DARK 1 // light samples whose diffuse AND specular coefficients are exactly 0 (the light is behind the surface) are not traced (light_is_dark())
+#endif
 #ifndef NR_ELIDE_TRANSPARENT
 #define NR_ELIDE_TRANSPARENT 1 // hits on fully transparent points skip their shadow rays and Phong (shade_hit())
 #endif
@@ -1121,6 +1124,18 @@ NR_DEV bool shadow_query(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, 
     return traverse<true, STATS, FEAT>(S, st, o, d, tlimit, dummy, filter, cnt);
 }
 #endif
+// A light sample on the far side of the surface: phong_material.rs:109-141 traces its shadow ray first and THEN multiplies the filter by
+// diffuse = kd * max(dot(l, n) as f32, 0) and, only `if scoeff > 0`, a specular term with scoeff = -dot(normalize(2 n (l.n) - l), dir) as f32.
+// Where (l.n as f32) <= 0 and scoeff <= 0 the sample adds light.color * (filter * 0) = +-0 to a sum that is never -0: the pixel does not depend on the
+// shadow ray (finite colours), so plain renders count it (rays_shadow stays the reference's number; rays_shadow_elided) and do not trace it.  dcoeff is
+// tested on the very expression the shading uses; scoeff's sign is decided WITHOUT the normalisation — the mirrored direction has length 1 up to
+// rounding (l, n unit), so the normalised dot differs from dot(ru, dir) by < 1e-14: beyond the 1e-9 margin the sign is certain, inside it the ray is traced.
+NR_DEV bool light_is_dark(d3 ldir, d3 normal, d3 dir) {
+    const double dln = dot(ldir, normal);
+    if ((float)dln > 0.0f) return false;
+    const d3 ru = (-ldir) + (normal * dln) * 2.0;
+    return dot(ru, dir) > 1e-9;
+}
 // `lsl` > 0 (light-parallel wave tiles, k_primary): 2^lsl consecutive lanes hold the SAME hit — they traced the same ray — and
 // share its light loop: lane slot j of the group traces the shadow rays of lights j, j + 2^lsl, ..., and the per-light sums are
 // then folded into `res` in light order by every lane of the group (`__shfl` from the lane that holds light l), i.e. exactly
@@ -1161,6 +1176,7 @@ NR_MAT_ATTR f4 material_compute(const DScene& S, Stack& st, const ShadeRec& m, R
                 filter = pre_filter;
             } else {
                 cnt.shadow++;
+                if (!STATS && NR_ELIDE_DARK && light_is_dark(ldir, normal, ray.d)) { cnt.elided++; continue; }
                 NR_TIC(tsq);
                 // kFeatPark: what the Phong terms below need of this hit waits in LDS while the shadow ray is traced (the values are the same
                 // bits afterwards; `in.n`, `point` and `ray.d` are the caller's objects, so its later uses read the reloaded registers too)
@@ -1343,6 +1359,8 @@ NR_DEV f3 shade_hit(const DScene& S, Stack& st, RayState& ray, uint32_t depth, u
             pre = true;
             NR_TOC(cyc_x[3], tsh);
             NR_TIC(tsq);
+            if (!STATS && NR_ELIDE_DARK && light_is_dark(ldir, is.n, ray.d)) { cnt.elided++; pre_lit = false; } // (as if shadowed: the sample's term is 0 either way)
+            else {
             // kFeatPark: the hit's record and the ray wait in LDS while the shadow ray is traced (the same bits come back)
             if ((FEAT & kFeatPark) && (FEAT & kFeatAlphaShadow)) {
                 st.park_d3(0, is.n); st.park_d3(6, ray.d); st.park_d(12, hit.t);
@@ -1352,6 +1370,7 @@ NR_DEV f3 shade_hit(const DScene& S, Stack& st, RayState& ray, uint32_t depth, u
             if ((FEAT & kFeatPark) && (FEAT & kFeatAlphaShadow)) {
                 is.n = st.unpark_d3(0); ray.d = st.unpark_d3(6); hit.t = st.unpark_d(12);
                 if (park_slots(FEAT) >= 24) { ray.o = st.unpark_d3(14); is.u = st.unpark_d(20); is.v = st.unpark_d(22); }
+            }
             }
             NR_TOC(cyc_shadow, tsq);
 #ifdef NR_PHASE_TIMING

@@ -1,7 +1,12 @@
-"""Hits that contribute nothing of their own to the pixel — a fully transparent point (opacity-map texel 0, node alpha 0: the holes of alpha-tested
+"""Shadow rays whose result is multiplied by exactly zero are counted, not traced, by plain renders (trace_device.h: shade_hit, light_is_dark).
+
+(1) Hits that contribute nothing of their own to the pixel — a fully transparent point (opacity-map texel 0, node alpha 0: the holes of alpha-tested
 foliage) or a perfect mirror (refl_mix 1): obj.rgb * (weight * alpha * (1 - mix)) = 0, scene.rs:179-190 — are not shaded by plain renders
 (trace_device.h: shade_hit): their shadow rays are COUNTED (NraysStats::rays_shadow stays the reference's number, rays_shadow_elided says how many
-were not traced) and the pixel must be the bit-identical one of the instrumented render, which traces and shades everything, and the oracle's."""
+were not traced) and the pixel must be the bit-identical one of the instrumented render, which traces and shades everything, and the oracle's.
+
+(2) Light samples behind the surface: diffuse = kd * max(l.n, 0) = 0 and, where the mirrored light direction also points away from the eye, no specular
+term either (phong_material.rs:109-141): the sample adds light.color * (filter * 0) whatever its shadow ray returns.  Every scene kind: same frames, same counts."""
 import ctypes as C
 import math
 
@@ -56,4 +61,41 @@ def test_hits_without_a_term_of_their_own_are_counted_not_traced(gpu, n_lights, 
             assert getattr(st, k) == getattr(ost, k), (k, getattr(st, k), getattr(ost, k))   # the reference's counts, traced or not
     assert stats[2].rays_shadow_elided == 0                                                    # the instrumented render traces everything
     assert 0 < stats[0].rays_shadow_elided == stats[1].rays_shadow_elided < stats[0].rays_shadow
-    assert stats[0].rays_shadow_elided % per_hit == 0                                          # whole hits: one ray per light sample each
+    assert stats[0].rays_shadow_elided >= per_hit                                              # (+ the samples of lights behind their surface)
+
+
+def _balls():
+    return su.balls_scene(tex_size=(64, 32))
+
+
+def _prims():
+    return su.primitives_scene(light_radius=0.1, nsample=10)
+
+
+def _mesh3():
+    return su.mesh_scene(alpha_mapped=False, n_lights=2)
+
+
+def _shapes():
+    return su.random_shapes_scene(3)
+
+
+@pytest.mark.parametrize("make,kw", [(_balls, {}), (_prims, {}), (_prims, dict(spp=2, window=1.0, seed=3)), (_mesh3, {}), (su.mesh_scene, {}), (_shapes, {})])
+def test_lights_behind_the_surface_are_counted_not_traced(gpu, make, kw):
+    import torch
+    lib = abi.load_hip_lib()
+    sc, cam = make()
+    p, _ = su.camera_params(cam, 200, 120, **kw)
+    ref, ost = oracle.render(sc.descriptor, p, 8)
+    out = torch.empty((120, 200, 3), dtype=torch.float32, device="cuda")
+    frames, stats = [], []
+    for fn in (lib.nrays_render_device, lib.nrays_render_device, lib.nrays_render_device_instrumented):
+        abi.check(fn(sc.device_handle(), C.byref(p), C.c_void_p(out.data_ptr()), None))
+        frames.append(out.cpu().numpy().copy()); stats.append(nr.get_stats(sc))
+    assert np.array_equal(frames[0], frames[2]) and np.array_equal(frames[1], frames[2])
+    assert float(np.abs(frames[0] - ref).max()) <= 1e-4
+    for st in stats:
+        for k in ("rays_primary", "rays_reflection", "rays_refraction", "rays_shadow"):
+            assert getattr(st, k) == getattr(ost, k), (k, getattr(st, k), getattr(ost, k))
+    assert stats[2].rays_shadow_elided == 0
+    assert 0 < stats[0].rays_shadow_elided == stats[1].rays_shadow_elided < stats[0].rays_shadow

@@ -21,6 +21,7 @@ NRAYS_BUILD_TIMES=1 timeout 200 python tools/build_times.py 2>&1 | grep -v "8 tr
 for s in balls sponza hairball; do timeout 500 python tools/pmc_collect.py $s gpurun_out/final/${R}_pmc_$s.json > /dev/null 2>&1; done
 timeout 400 python tools/kbench.py --scenes balls,ballsaway,primitives,sponza,sponza8,hairball --steps 30 > gpurun_out/final/${R}_kbench_final.log 2>&1
 timeout 600 python tools/bigconfigs.py > gpurun_out/final/${R}_bigconfigs.log 2>&1
+timeout 600 python tools/tile_scaling.py sponza8_4k 2>&1 | grep -v amdgpu.ids > gpurun_out/final/${R}_tile_scaling.log
 python - <<'PY'
 import json, csv, glob
 d=json.loads(open('gpurun_out/final/r05_bench_final.json').read().strip().splitlines()[-1])

@@ -69,7 +69,7 @@ def run_one(scene_name, steps, width, height, check):
     res = {"scene": scene_name, "res": [width, height], "ms": round(dt * 1e3, 4), "mrays_s": round(st.total_rays() / dt / 1e6, 1),
            "rays": st.total_rays(), "primary_ms": round(ts.kernel_ms_primary, 4), "gpu_ms": round(ts.kernel_ms_total, 4),
            "node_per_ray": round(st.node_tests / st.total_rays(), 1), "tri_per_ray": round(st.tri_tests / st.total_rays(), 2),
-           "gens": st.generations, "build_s": round(t_build, 2),
+           "gens": st.generations, "build_s": round(t_build, 2), "shadow": st.rays_shadow, "shadow_not_traced": ts.rays_shadow_elided,
            "GBs_alg": round(st.algorithmic_bytes(width, height) / (ts.kernel_ms_total * 1e-3) / 1e9, 1) if ts.kernel_ms_total > 0 else None}
     if check:
         import oracle
