@@ -439,9 +439,13 @@ __global__ void __launch_bounds__(kBlock, OCC ? NR_OCC3_AS : waves_per_simd(FEAT
         { const uint32_t dt_ = (uint32_t)__builtin_amdgcn_s_memrealtime() - dbg_tile_r0;
           if (dbg_worked) { dbg_work_ticks += dt_; if (dt_ > dbg_longest_ticks) dbg_longest_ticks = dt_; } else { dbg_miss_ticks += dt_; dbg_miss_tiles++; } }
 #endif
-        if (R.tile_cost && lane == 0u && part == 0u) { // wave cycles spent on this tile, for the next frame's order
-            unsigned long long dt = ((__builtin_readcyclecounter() - tile_t0) >> 4) << lsl; // (a light-parallel tile: its first part stands for all)
-            R.tile_cost[wt] = dt > 0xffffffffULL ? 0xffffffffu : (uint32_t)dt;
+        if (R.tile_cost && lane == 0u) { // wave cycles spent on this tile, for the next frame's order
+            unsigned long long dt = ((__builtin_readcyclecounter() - tile_t0) >> 4) << lsl;
+            const uint32_t c = dt > 0xffffffffULL ? 0xffffffffu : (uint32_t)dt;
+            // a light-parallel tile: its most expensive part stands for all (the array is cleared before a frame that records into split entries) — the
+            // first part alone is eight of the tile's pixels, and a tile priced by a cheap row stayed whole and late in the order: one rank of eight
+            // of config 4 ran 1.82 ms for 1.25 (profiles/r05_rank_occupancy.log)
+            if (kLightSplit && lsl) atomicMax(&R.tile_cost[wt], c); else R.tile_cost[wt] = c;
         }
       }
       if (grab == 1u) pending = issue_grab(work_counters, victim, grab);
@@ -1013,10 +1017,12 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
     int occ = 0;
     if (!instrumented && (sc->features == 6 || sc->features == 7 || sc->features == 22 || sc->features == 23) && lane_log2 == 0u) {
         const uint64_t wave_tiles = (uint64_t)ntiles * 4u, waves2 = (uint64_t)sc->num_cus * 8u;
-        // (multi-light frames: from 12 wave tiles per resident wave on — an owner's eighth of a 4K frame is as long as its longest tile even
-        // with that tile split, and ran 1.9 ms at two waves against 2.0 - 2.9 ms at three: profiles/r04_tile_scaling.log)
+        // (multi-light frames: from 6 wave tiles per resident wave on.  Round 5, after the shadow rays that are multiplied by 0 stopped being traced
+        // (light_is_dark()): an owner's eighth of a 4K frame, 16 320 wave tiles, runs 1.22 - 1.29 ms at three waves against 1.40 - 1.44 at two, half a
+        // 1080p frame 1.48 against 1.74; at 8 160 - 8 640 wave tiles the frame is as long as its longest split tile and two waves win, 1.10 / 0.97 ms
+        // against 1.46 / 1.24: profiles/r05_rank_occupancy.log.  Round 4's threshold was 12: the eighth then ran 1.9 ms at two against 2.0 - 2.9.)
         const bool multi = (sc->features & kFeatMultiSample) && sc->light_lsl && sc->light_split_factor != 0.0f;
-        occ = wave_tiles >= (multi ? 12u : 24u) * waves2 ? 3 : 0;
+        occ = wave_tiles >= (multi ? 6u : 24u) * waves2 ? 3 : 0;
         if (sc->occ_override >= 0) occ = sc->occ_override == 3 ? 3 : 0;
     }
     uint32_t grid_primary = std::min<uint32_t>(std::min<uint32_t>(((ntiles + 7u) / 8u) * 8u, (uint32_t)kMaxGrid),
@@ -1126,6 +1132,7 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
                 sc->order_valid = true; sc->order_key = key; sc->order_cam = seeded ? ~cam : sc->cost_cam; // (a guessed order is replaced by the recorded one on the next frame)
             }
             R.tile_cost = sc->d_tile_cost;
+            if (split_lsl && R.tile_order) HIP_TRY(hipMemsetAsync(sc->d_tile_cost, 0, (size_t)nwt * sizeof(uint32_t), stream)); // (after k_tile_order read it: split entries record by atomicMax)
             sc->cost_key = key; sc->cost_cam = cam; sc->cost_valid = true;
         }
     }
