@@ -216,11 +216,17 @@ __device__ inline void make_task(Task& c, uint32_t first, uint32_t count, int32_
 }
 
 // ---- stage 1: triangle records ----------------------------------------------------------------------------------------
-struct PartDev { const double* vertices; const double* uvs; const uint32_t* indices; uint32_t num_vertices, num_triangles, node_id, tri_base; };
+struct PartDev { const double* vertices; const double* uvs; const uint32_t* indices; uint32_t num_vertices, num_triangles, node_id, tri_base, block_base, pad; };
 
-__global__ __launch_bounds__(256) void k_tri_records(PartDev part, TriRec* recs, TriUv* uvs, float* tbox, double* part_area, double* part_tri2,
-                                                     uint32_t block_base, Counters* ctr) {
-    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+// One launch over all the meshes of the BLAS (a merged group of the sponza stand-in: 270 parts — one launch per part was 1.7 ms of an 8 ms build): block b serves the
+// part with the largest block_base <= b; the per-block sums are those of the per-part launches (same triangles per block, same fixed tree).
+__global__ __launch_bounds__(256) void k_tri_records(const PartDev* __restrict__ parts, uint32_t nparts, TriRec* recs, TriUv* uvs, float* tbox, double* part_area, double* part_tri2,
+                                                     Counters* ctr) {
+    uint32_t lo = 0, hi = nparts;
+    while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (parts[mid].block_base <= blockIdx.x) lo = mid; else hi = mid; }
+    const PartDev part = parts[lo];
+    const uint32_t block_base = part.block_base, local_block = blockIdx.x - block_base;
+    const uint32_t t = local_block * 256u + threadIdx.x;
     double ha = 0.0, ta = 0.0;
     float v12[12]; init12(v12);
     uint32_t err = 0;
@@ -259,7 +265,7 @@ __global__ __launch_bounds__(256) void k_tri_records(PartDev part, TriRec* recs,
     s_a[threadIdx.x] = ha; s_t[threadIdx.x] = ta;
     __syncthreads();
     for (uint32_t s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) { s_a[threadIdx.x] += s_a[threadIdx.x + s]; s_t[threadIdx.x] += s_t[threadIdx.x + s]; } __syncthreads(); }
-    if (threadIdx.x == 0) { part_area[block_base + blockIdx.x] = s_a[0]; part_tri2[block_base + blockIdx.x] = s_t[0]; }
+    if (threadIdx.x == 0) { part_area[block_base + local_block] = s_a[0]; part_tri2[block_base + local_block] = s_t[0]; }
     wave_reduce12(v12);
     if (lane_id() == 0 && v12[0] <= v12[6]) for (int a = 0; a < 3; ++a) { atomicMin(&ctr->bounds[a], enc(v12[a])); atomicMax(&ctr->bounds[6 + a], enc(v12[6 + a])); }
     const unsigned long long any = __ballot(err != 0);
@@ -839,7 +845,7 @@ int build_impl(const std::vector<DeviceMeshPart>& parts, const DeviceBuildOption
     size_t cub_bytes = 0; // what the prefix sum over the per-triangle reference counts needs
     DB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, cub_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)(n + 1)));
     bytes1 += padded<TriRec>(n) + padded<TriUv>(n) + padded<float>(6 * n) + 2 * padded<double>(nblocks_tri) + padded<Counters>(1) + 2 * padded<uint32_t>(n + 1) +
-              padded<uint32_t>(kHistBins) + padded<SplitFrame>(frame_count) + padded<char>(cub_bytes) + 4096;
+              padded<uint32_t>(kHistBins) + padded<SplitFrame>(frame_count) + padded<char>(cub_bytes) + padded<PartDev>(parts.size()) + 4096;
     DB_TRY(a1.reserve(bytes1));
     sw.lap("allocation (phase 1)");
     {   // A merged group (the sponza stand-in: 270 meshes under one isometry, ~800 small arrays) paid one synchronous hipMemcpy per array — 4-5 ms of
@@ -880,22 +886,26 @@ int build_impl(const std::vector<DeviceMeshPart>& parts, const DeviceBuildOption
     uint32_t* counts = a1.take<uint32_t>(n + 1); uint32_t* offsets = a1.take<uint32_t>(n + 1); uint32_t* hist = a1.take<uint32_t>(kHistBins);
     SplitFrame* frames = a1.take<SplitFrame>(frame_count);
     void* cub_tmp1 = a1.take<char>(cub_bytes + 16);
-    if (!frames || !cub_tmp1) { err = "device BLAS build: arena overflow (phase 1)"; return NRAYS_ERR_OOM; }
+    PartDev* dparts = a1.take<PartDev>(parts.size());
+    if (!frames || !cub_tmp1 || !dparts) { err = "device BLAS build: arena overflow (phase 1)"; return NRAYS_ERR_OOM; }
     sw.lap("upload of the mesh arrays");
     Counters h_ctr; std::memset(&h_ctr, 0, sizeof h_ctr);
     for (int k = 0; k < 6; ++k) { h_ctr.bounds[k] = 0xffffffffu; h_ctr.bounds[6 + k] = 0u; }
     h_ctr.root_ref = kEmptyChild;
     DB_TRY(hipMemcpy(ctr, &h_ctr, sizeof h_ctr, hipMemcpyHostToDevice));
     {
+        std::vector<PartDev> hp;
         uint32_t tri_base = 0, block_base = 0;
         for (const DeviceMeshPart& p : parts) {
             if (p.num_triangles == 0) continue;
             PartDev d; d.vertices = (const double*)uploads[p.vertices].second; d.uvs = p.uvs ? (const double*)uploads[p.uvs].second : nullptr;
             d.indices = (const uint32_t*)uploads[p.indices].second; d.num_vertices = p.num_vertices; d.num_triangles = p.num_triangles; d.node_id = p.node_id; d.tri_base = tri_base;
-            const uint32_t nb = (p.num_triangles + 255u) / 256u;
-            hipLaunchKernelGGL(k_tri_records, dim3(nb), dim3(256), 0, 0, d, recs, uvs, tbox, part_area, part_tri2, block_base, ctr);
-            tri_base += p.num_triangles; block_base += nb;
+            d.block_base = block_base; d.pad = 0;
+            hp.push_back(d);
+            tri_base += p.num_triangles; block_base += (p.num_triangles + 255u) / 256u;
         }
+        DB_TRY(hipMemcpy(dparts, hp.data(), hp.size() * sizeof(PartDev), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_tri_records, dim3(block_base), dim3(256), 0, 0, (const PartDev*)dparts, (uint32_t)hp.size(), recs, uvs, tbox, part_area, part_tri2, ctr);
     }
     DB_TRY(hipGetLastError());
     DB_TRY(hipMemcpy(&h_ctr, ctr, sizeof h_ctr, hipMemcpyDeviceToHost));
