@@ -55,6 +55,9 @@ constexpr int32_t kParked = (int32_t)0x80000002;   // a lane that yielded its no
 #ifndef NR_ELIDE_DARK
 #define NR_ELIDE_DARK 1 // light samples whose diffuse AND specular coefficients are exactly 0 (the light is behind the surface) are not traced (light_is_dark())
 #endif
+#ifndef NR_ELIDE_DARK_MATTE
+#define NR_ELIDE_DARK_MATTE 1 // ... and for a material without a specular colour the sign of l.n alone decides (no_specular())
+#endif
 #ifndef NR_ELIDE_TRANSPARENT
 #define NR_ELIDE_TRANSPARENT 1 // hits on fully transparent points skip their shadow rays and Phong (shade_hit())
 #endif
@@ -1130,12 +1133,16 @@ NR_DEV bool shadow_query(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, 
 // shadow ray (finite colours), so plain renders count it (rays_shadow stays the reference's number; rays_shadow_elided) and do not trace it.  dcoeff is
 // tested on the very expression the shading uses; scoeff's sign is decided WITHOUT the normalisation — the mirrored direction has length 1 up to
 // rounding (l, n unit), so the normalised dot differs from dot(ru, dir) by < 1e-14: beyond the 1e-9 margin the sign is certain, inside it the ray is traced.
-NR_DEV bool light_is_dark(d3 ldir, d3 normal, d3 dir) {
+// A material without a specular colour (Ks 0 0 0, most of an OBJ scene's materials): specular = ks * scoeff^shininess = 0 for every scoeff in (0, 1], and
+// diffuse + 0 = diffuse — the sample is dark as soon as the light is behind the surface.
+NR_DEV bool light_is_dark(d3 ldir, d3 normal, d3 dir, bool no_specular) {
     const double dln = dot(ldir, normal);
     if ((float)dln > 0.0f) return false;
+    if (no_specular) return true;
     const d3 ru = (-ldir) + (normal * dln) * 2.0;
     return dot(ru, dir) > 1e-9;
 }
+NR_DEV bool no_specular(const ShadeRec& m) { return NR_ELIDE_DARK_MATTE && m.ks[0] == 0.0f && m.ks[1] == 0.0f && m.ks[2] == 0.0f && m.shininess >= 0.0f; } // (a negative exponent could make 0 * inf)
 // `lsl` > 0 (light-parallel wave tiles, k_primary): 2^lsl consecutive lanes hold the SAME hit — they traced the same ray — and
 // share its light loop: lane slot j of the group traces the shadow rays of lights j, j + 2^lsl, ..., and the per-light sums are
 // then folded into `res` in light order by every lane of the group (`__shfl` from the lane that holds light l), i.e. exactly
@@ -1151,6 +1158,7 @@ NR_MAT_ATTR f4 material_compute(const DScene& S, Stack& st, const ShadeRec& m, R
     else if (in.has_uv && m.alpha_tex.texels) alpha = tex_sample<STATS>(m.alpha_tex, in.u, in.v, cnt).w;
     f3 res = F3(m.ka[0] * tex.x, m.ka[1] * tex.y, m.ka[2] * tex.z);
     d3 normal = in.n;
+    const bool no_spec = no_specular(m);
     // one light: the sum over its samples (light.rs:57-63 + phong_material.rs:108-146)
     auto light_sum = [&](uint32_t li) -> f3 {
         const LightRec& light = S.lights[li];
@@ -1176,7 +1184,7 @@ NR_MAT_ATTR f4 material_compute(const DScene& S, Stack& st, const ShadeRec& m, R
                 filter = pre_filter;
             } else {
                 cnt.shadow++;
-                if (!STATS && NR_ELIDE_DARK && light_is_dark(ldir, normal, ray.d)) { cnt.elided++; continue; }
+                if (!STATS && NR_ELIDE_DARK && light_is_dark(ldir, normal, ray.d, no_spec)) { cnt.elided++; continue; }
                 NR_TIC(tsq);
                 // kFeatPark: what the Phong terms below need of this hit waits in LDS while the shadow ray is traced (the values are the same
                 // bits afterwards; `in.n`, `point` and `ray.d` are the caller's objects, so its later uses read the reloaded registers too)
@@ -1359,7 +1367,7 @@ NR_DEV f3 shade_hit(const DScene& S, Stack& st, RayState& ray, uint32_t depth, u
             pre = true;
             NR_TOC(cyc_x[3], tsh);
             NR_TIC(tsq);
-            if (!STATS && NR_ELIDE_DARK && light_is_dark(ldir, is.n, ray.d)) { cnt.elided++; pre_lit = false; } // (as if shadowed: the sample's term is 0 either way)
+            if (!STATS && NR_ELIDE_DARK && light_is_dark(ldir, is.n, ray.d, no_specular(S.shade[node_id]))) { cnt.elided++; pre_lit = false; } // (as if shadowed: the sample's term is 0 either way)
             else {
             // kFeatPark: the hit's record and the ray wait in LDS while the shadow ray is traced (the same bits come back)
             if ((FEAT & kFeatPark) && (FEAT & kFeatAlphaShadow)) {

@@ -80,7 +80,20 @@ def _shapes():
     return su.random_shapes_scene(3)
 
 
-@pytest.mark.parametrize("make,kw", [(_balls, {}), (_prims, {}), (_prims, dict(spp=2, window=1.0, seed=3)), (_mesh3, {}), (su.mesh_scene, {}), (_shapes, {})])
+def _matte():
+    """No specular colour (Ks 0 0 0): every light behind the surface is dark, whatever the mirrored direction."""
+    pts, idx, uvs = su.torus_mesh()
+    matte = nr.PhongMaterial((0.1, 0.1, 0.1), (0.9, 0.8, 0.7), (0.0, 0.0, 0.0), su.checker_texture(64, 8), None, 40.0)
+    shiny = nr.PhongMaterial((0.1, 0.1, 0.1), (0.5, 0.6, 0.9), (1.0, 1.0, 1.0), None, None, 20.0)
+    fl = su.f32_exact([[-6, -1.25, -6], [6, -1.25, -6], [6, -1.25, 6], [-6, -1.25, 6]])
+    nodes = [nr.SceneNode(matte, 0.0, 0.0, 1.0, 1.0, nr.Isometry3((0.0, 0.0, 0.0), (0.3, 0.2, 0.0)), nr.TriMesh(pts, idx, uvs)),
+             nr.SceneNode(shiny, 0.0, 0.0, 1.0, 1.0, nr.Isometry3((0.0, 0.0, 0.0)), nr.TriMesh(fl, np.asarray([[0, 2, 1], [0, 3, 2]], dtype=np.uint32), None)),
+             nr.SceneNode(matte, 0.0, 0.0, 1.0, 1.0, nr.Isometry3((2.8, 0.2, 0.5)), nr.Ball(0.7))]
+    lights = [nr.Light((3.0, 6.0, -6.0), 0.0, 1, (0.7, 0.7, 0.7)), nr.Light((-4.0, -0.5, 4.0), 0.0, 1, (0.5, 0.5, 0.6)), nr.Light((0.0, 0.5, 8.0), 0.2, 4, (0.4, 0.4, 0.4))]
+    return nr.Scene(nodes, lights, (0.2, 0.3, 0.5)), dict(eye=(0.5, 3.0, -9.0), at=(0.0, 0.0, 0.0), fovy=40.0)
+
+
+@pytest.mark.parametrize("make,kw", [(_balls, {}), (_prims, {}), (_prims, dict(spp=2, window=1.0, seed=3)), (_mesh3, {}), (su.mesh_scene, {}), (_shapes, {}), (_matte, {}), (_matte, dict(spp=2, window=1.0, seed=9))])
 def test_lights_behind_the_surface_are_counted_not_traced(gpu, make, kw):
     import torch
     lib = abi.load_hip_lib()
