@@ -1,47 +1,64 @@
 #!/usr/bin/env python
-"""Where a kernel's scratch (spill) accesses sit: instructions and scratch loads / stores of one k_primary instantiation by loop depth (LLVM's "Depth=" annotations
-in the assembly), and every block of depth >= 5 — the node loop, the triangle loop — with its instruction mix.  CPU only (hipcc -S, ~1.5 min).
+"""Instruction mix of the BVH node loops of one kernel in a hipcc -S listing.
 
-  python tools/isa_loops.py "k_primaryILb0ELi2ELb1ELi0E" ["k_primaryILb0ELi214ELb1ELi3E" ...]      (mangled-name fragments)
+  python tools/isa_loops.py listing.s 'k_primaryILb0ELi6ELb1E' [--dump N]
+
+A node loop is recognised by its header block holding >= 6 global_load_dwordx4 (the six plane fetches of a BvhNode);
+the loop body is every block LLVM annotates with that header.  Prints VALU / SALU / branch / VMEM / LDS
+counts per loop (static counts: both sides of the rare paths are included).
 """
-import os, re, subprocess, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
-import __graft_entry__ as g
+import re
+import sys
 
-asm = "/tmp/nrays_isa.s"
-if not os.path.exists(asm) or os.environ.get("REBUILD"):
-    flags = [f for f in g.HIP_FLAGS if f != "-fPIC"]
-    subprocess.check_call(["/opt/rocm/bin/hipcc"] + flags + ["-DNR_ONLY_MESH", "-S", "--cuda-device-only", "-o", asm, os.path.join(g.CSRC, "nrays_hip.hip")], stderr=subprocess.DEVNULL)
-text = open(asm).read().split("\n")
-for frag in sys.argv[1:] or ["k_primaryILb0ELi2ELb1ELi0E"]:
-    start = next(i for i, l in enumerate(text) if l.startswith("_Z") and frag in l.split(":")[0] and ":" in l)
-    end = next(i for i in range(start, len(text)) if text[i].startswith(".Lfunc_end"))
-    blocks, cur = [], dict(name="entry", depth=0, ins=0, ld=0, st=0, vmem=0, smem=0, lds=0, f64=0)
-    blocks.append(cur)
-    for l in text[start + 1:end]:
-        m = re.match(r"^(\.LBB\d+_\d+):(.*)", l)
-        if m:
-            cur = dict(name=m.group(1), depth=0, ins=0, ld=0, st=0, vmem=0, smem=0, lds=0, f64=0); blocks.append(cur)
-            d = re.search(r"Depth=(\d+)", l); cur["depth"] = int(d.group(1)) if d else 0
-            continue
-        s = l.strip()
-        if s.startswith(";"):
-            d = re.search(r"Depth=(\d+)", s)
-            if d: cur["depth"] = max(cur["depth"], int(d.group(1)))
-            continue
-        if not s or s.startswith("."): continue
-        cur["ins"] += 1
-        if s.startswith("scratch_load"): cur["ld"] += 1
-        elif s.startswith("scratch_store"): cur["st"] += 1
-        elif s.startswith(("global_", "flat_", "buffer_")): cur["vmem"] += 1
-        elif s.startswith(("s_load", "s_buffer_load")): cur["smem"] += 1
-        elif s.startswith("ds_"): cur["lds"] += 1
-        if "_f64" in s: cur["f64"] += 1
-    print("== %s: %d blocks, %d instructions, scratch loads %d, stores %d" % (frag, len(blocks), sum(b["ins"] for b in blocks), sum(b["ld"] for b in blocks), sum(b["st"] for b in blocks)))
-    for d in sorted({b["depth"] for b in blocks}):
-        bs = [b for b in blocks if b["depth"] == d]
-        print("  loop depth %d: %3d blocks %5d instructions   scratch loads %3d stores %3d" % (d, len(bs), sum(b["ins"] for b in bs), sum(b["ld"] for b in bs), sum(b["st"] for b in bs)))
-    print("  blocks of depth >= 5 with >= 20 instructions (name, depth, instructions, scratch ld/st, vector / scalar / LDS memory, f64 ops):")
-    for b in blocks:
-        if b["depth"] >= 5 and b["ins"] >= 20:
-            print("    %-12s d%d %4d   scratch %2d/%-2d  vmem %2d smem %2d lds %2d  f64 %3d" % (b["name"], b["depth"], b["ins"], b["ld"], b["st"], b["vmem"], b["smem"], b["lds"], b["f64"]))
+
+def kernel_lines(path, pat):
+    lines = open(path).read().splitlines()
+    start = next(i for i, l in enumerate(lines) if re.match(r"^_Z\w*" + pat + r"\w*:", l))
+    end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith(".end_amdhsa_kernel") or lines[i].startswith(".Lfunc_end"))
+    return lines[start:end]
+
+
+def classify(op):
+    if op.startswith("v_"): return "valu"
+    if op.startswith("s_cbranch") or op.startswith("s_branch"): return "branch"
+    if op.startswith("s_waitcnt") or op.startswith("s_nop"): return "wait"
+    if op.startswith("s_"): return "salu"
+    if op.startswith("global_") or op.startswith("buffer_") or op.startswith("flat_") or op.startswith("scratch_"): return "vmem"
+    if op.startswith("ds_"): return "lds"
+    return "other"
+
+
+def main():
+    path, pat = sys.argv[1], sys.argv[2]
+    dump = int(sys.argv[sys.argv.index("--dump") + 1]) if "--dump" in sys.argv else -1
+    L = kernel_lines(path, pat)
+    labels = {}
+    for i, l in enumerate(L):
+        m = re.match(r"^(\.LBB\d+_\d+):", l)
+        if m: labels[m.group(1)] = i
+    heads = []
+    for lab, i in labels.items():
+        j, n = i + 1, 0
+        while j < len(L) and not re.match(r"^\.LBB", L[j]):
+            n += "global_load_dwordx4" in L[j]; j += 1
+        if n >= 6: heads.append((i, lab))
+    for k, (i, lab) in enumerate(sorted(heads)):
+        # LLVM annotates every block of a loop with "in Loop: Header=BBx_y"; the header itself carries "Parent Loop" / "Loop Header"
+        tag = "Header=" + lab[2:]
+        body, inside = [], False
+        for l in L:
+            m = re.match(r"^(\.LBB\d+_\d+):(.*)", l)
+            if m:
+                inside = m.group(1) == lab or (tag + " ") in (m.group(2) + " ")
+                continue
+            if inside:
+                t = l.split(";")[0].strip()
+                if t and not t.startswith("."): body.append(t)
+        mix = {}
+        for l in body: mix[classify(l.split()[0])] = mix.get(classify(l.split()[0]), 0) + 1
+        print(f"loop {k} {lab}: {len(body)} instructions", dict(sorted(mix.items())))
+        if k == dump: print("\n".join(body))
+
+
+if __name__ == "__main__":
+    main()
