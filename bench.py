@@ -590,8 +590,9 @@ def tiled_measure(name, W, H, steps, warmup, rank, world, owners):
         abi.check(lib.nrays_render_device(scene.device_handle(), C.byref(full), C.c_void_p(direct.data_ptr()), None))
         torch.cuda.synchronize()
         check = bool(torch.equal(direct, frame))
+        elided = int(nr.get_stats(scene).rays_shadow_elided)  # the plain frame's shadow rays that are multiplied by 0: counted, not traced
         abi.check(lib.nrays_render_device_instrumented(scene.device_handle(), C.byref(full), C.c_void_p(direct.data_ptr()), None))
-        traced = nr.get_stats(scene).rays_traced()  # counted by instrumented renders only
+        traced = nr.get_stats(scene).rays_traced() - elided  # (rays_primary_traced is counted by instrumented renders only)
     res = None
     if rank == 0:
         owned = len(tiling.owned_rows(H, band, owner0, owners))
@@ -603,7 +604,7 @@ def tiled_measure(name, W, H, steps, warmup, rank, world, owners):
                           "tiled_frame_identical_to_single_gpu_render": check,
                           "rays_per_frame": {"total": int(rays_total), "primary": int(rays_t[1].item()), "reflection": int(rays_t[2].item()),
                                              "refraction": int(rays_t[3].item()), "shadow": int(rays_t[4].item())},
-                          "rays_traced_per_frame": int(traced)},
+                          "rays_traced_per_frame": int(traced), "rays_shadow_counted_not_traced_per_frame": elided},
                # owner 0's tile kernel; no counters at N > 1 (the profiler leg runs at N = 1 only)
                "roofline": roofline_block(pk, tst, W, owned, lib.nrays_scene_device_bytes(h0), None, None, tile_costs)}
     ss.close()
