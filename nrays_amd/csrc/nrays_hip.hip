@@ -143,6 +143,9 @@ constexpr int waves_per_simd(int feat) { return (feat & ~(kFeatMultiSample | kFe
 // OCC != 0: the alpha-shadow mesh permutations also exist at three waves per SIMD (168 VGPRs, ~64 dwords of scratch per lane): a
 // wave then runs slower, which lengthens a frame that is as long as its longest tile (sponza 1080p: 1.40 -> 1.67 ms) and shortens a
 // frame that is bound by the sum of its tiles (sponza 4K: 4.12 -> 3.65 ms, config 4: 14.6 -> 12.5 ms) — render_impl chooses per frame.
+#ifndef NR_PIXEL_SPLIT
+#define NR_PIXEL_SPLIT 1 // long tiles of one-light alpha-mapped mesh frames are split by pixels (the light-parallel machinery with one light)
+#endif
 #ifndef NR_OCC3_AS
 #define NR_OCC3_AS 3 // waves per SIMD the OCC = 3 permutations are compiled and launched for (experiments: 4)
 #endif
@@ -203,7 +206,9 @@ __global__ void __launch_bounds__(kBlock, OCC ? NR_OCC3_AS : waves_per_simd(FEAT
 #endif
 
     const uint32_t lane = threadIdx.x & 63u;
-    constexpr bool kLightSplit = !STATS && (FEAT & kFeatMultiSample) && (FEAT & kFeatMesh) && !(FEAT & kFeatDouble);
+    // (one-light scenes with transparent nodes too — NR_PIXEL_SPLIT: a part is then 64 >> lsl PIXELS of the tile, every pixel's 2^lsl lanes tracing the same rays; what it
+    // buys is that the deep, divergent chains through alpha-mapped layers of 8 pixels serialise in a wave instead of those of 64)
+    constexpr bool kLightSplit = !STATS && (FEAT & kFeatMesh) && !(FEAT & kFeatDouble) && ((FEAT & kFeatMultiSample) || (NR_PIXEL_SPLIT && (FEAT & kFeatAlphaShadow)));
 #ifdef NR_DEBUG_TILE_COSTS
     const uint32_t dbg_t_entry = (uint32_t)__builtin_amdgcn_s_memrealtime();
     const unsigned long long dbg_c_entry = __builtin_readcyclecounter();
@@ -440,7 +445,10 @@ __global__ void __launch_bounds__(kBlock, OCC ? NR_OCC3_AS : waves_per_simd(FEAT
           if (dbg_worked) { dbg_work_ticks += dt_; if (dt_ > dbg_longest_ticks) dbg_longest_ticks = dt_; } else { dbg_miss_ticks += dt_; dbg_miss_tiles++; } }
 #endif
         if (R.tile_cost && lane == 0u) { // wave cycles spent on this tile, for the next frame's order
-            unsigned long long dt = ((__builtin_readcyclecounter() - tile_t0) >> 4) << lsl;
+            // (a part's cycles stand for the tile's: x 2^lsl for a light-parallel part; x 3 for a part of a one-light tile — 8 of its pixels: measured, a whole foliage tile takes
+            // 2 - 3 parts' time — so that a tile a first guess split without need, e.g. in a 4K frame, is whole again once its cost is known)
+            unsigned long long dt = (__builtin_readcyclecounter() - tile_t0) >> 4;
+            if (kLightSplit && lsl) dt = (FEAT & kFeatMultiSample) ? dt << lsl : dt * 3u;
             const uint32_t c = dt > 0xffffffffULL ? 0xffffffffu : (uint32_t)dt;
             // a light-parallel tile: its most expensive part stands for all (the array is cleared before a frame that records into split entries) — the
             // first part alone is eight of the tile's pixels, and a tile priced by a cheap row stayed whole and late in the order: one rank of eight
@@ -1022,7 +1030,12 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
         // 1080p frame 1.48 against 1.74; at 8 160 - 8 640 wave tiles the frame is as long as its longest split tile and two waves win, 1.10 / 0.97 ms
         // against 1.46 / 1.24: profiles/r05_rank_occupancy.log.  Round 4's threshold was 12: the eighth then ran 1.9 ms at two against 2.0 - 2.9.)
         const bool multi = (sc->features & kFeatMultiSample) && sc->light_lsl && sc->light_split_factor != 0.0f;
-        occ = wave_tiles >= (multi ? 6u : 24u) * waves2 ? 3 : 0;
+        // One light: from 14 wave tiles per resident wave on (round 5: the 1080p sponza stand-in, 32 640 wave tiles, 1.125 ms at three waves against 1.23 at two — its sum of
+        // tile cycles per resident wave, 1.14 ms at two waves, had passed its longest tile, 0.89; at 1600 x 900, 22 800 wave tiles, the longest tile still leads and two waves
+        // win, 0.93 against 1.12: profiles/r05_rank_occupancy.log.  Round 4's threshold was 24.)
+        // (with the long tiles of one-light frames split by pixels, NR_PIXEL_SPLIT, the longest tile stops leading earlier: 22 800 wave tiles 0.86 ms at three waves against 0.95,
+        // 14 400 wave tiles 0.75 against 0.73 — from 9 on)
+        occ = wave_tiles >= (multi ? 6u : (NR_PIXEL_SPLIT && sc->light_lsl ? 9u : 14u)) * waves2 ? 3 : 0;
         if (sc->occ_override >= 0) occ = sc->occ_override == 3 ? 3 : 0;
     }
     uint32_t grid_primary = std::min<uint32_t>(std::min<uint32_t>(((ntiles + 7u) / 8u) * 8u, (uint32_t)kMaxGrid),
@@ -1091,7 +1104,10 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
     if (lpt) {
         const uint32_t nwt = std::max<uint32_t>(1u, lane_log2 ? win_units : win_units * 4u);
         // light-parallel tiles (DRender::light_lsl): multi-light mesh scenes; the order array then holds up to 2^lsl entries per tile
-        const uint32_t split_lsl = (sc->light_lsl && sc->light_split_factor != 0.0f && !instrumented) ? sc->light_lsl : 0u;
+        // (one-light frames, NR_PIXEL_SPLIT: only while a single tile can lead the frame — below 24 wave tiles per resident wave at two waves per SIMD; beyond, no tile comes near
+        // the frame's work per wave and the split machinery costs 0.7 %: profiles/r05_pixel_split_ab.log)
+        const bool pixel_split_only = sc->light_lsl && !(sc->features & kFeatMultiSample);
+        const uint32_t split_lsl = (sc->light_lsl && sc->light_split_factor != 0.0f && !instrumented && !(pixel_split_only && (uint64_t)nwt >= 24ull * (uint64_t)sc->num_cus * 8ull)) ? sc->light_lsl : 0u;
         if (nwt > sc->tile_slots) {
             if (sc->d_tile_cost) { (void)hipFree(sc->d_tile_cost); sc->d_tile_cost = nullptr; }
             if (sc->d_tile_order) { (void)hipFree(sc->d_tile_order); sc->d_tile_order = nullptr; }
@@ -1455,7 +1471,8 @@ int nrays_scene_create(const NraysSceneDesc* desc, NraysScene** out_scene) {
     if (const char* e = getenv("NRAYS_LPT")) sc->lpt_enabled = atoi(e) != 0;
     if (const char* e = getenv("NRAYS_SCREEN_CULL")) sc->cull_enabled = atoi(e) != 0;
     { const int f = sc->features; // multi-light mesh scenes without double branching: 2, 4 or 8 lanes per pixel in a split tile
-      if ((f & kFeatMultiSample) && (f & kFeatMesh) && !(f & kFeatDouble) && h.lights.size() >= 2) { uint32_t l = 1; while (l < 3u && (2u << l) <= h.lights.size()) ++l; sc->light_lsl = l; } }
+      if ((f & kFeatMultiSample) && (f & kFeatMesh) && !(f & kFeatDouble) && h.lights.size() >= 2) { uint32_t l = 1; while (l < 3u && (2u << l) <= h.lights.size()) ++l; sc->light_lsl = l; }
+      else if (NR_PIXEL_SPLIT && !(f & kFeatMultiSample) && (f & kFeatMesh) && (f & kFeatAlphaShadow) && !(f & kFeatDouble)) sc->light_lsl = 3; } // pixel split: 8 pixels per part
     if (const char* e = getenv("NRAYS_LIGHT_SPLIT")) sc->light_split_factor = (float)atof(e);
     if (const char* e = getenv("NRAYS_OCC")) sc->occ_override = atoi(e);
     if (const char* e = getenv("NRAYS_WAVEFRONT")) sc->wavefront_mode = atoi(e);

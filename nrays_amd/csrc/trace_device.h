@@ -1363,11 +1363,11 @@ NR_DEV f3 shade_hit(const DScene& S, Stack& st, RayState& ray, uint32_t depth, u
             d3 ldir = pos - point;
             double nrm = norm(ldir);
             ldir = ldir / nrm;
-            cnt.shadow++;
+            if (count_me) cnt.shadow++;
             pre = true;
             NR_TOC(cyc_x[3], tsh);
             NR_TIC(tsq);
-            if (!STATS && NR_ELIDE_DARK && light_is_dark(ldir, is.n, ray.d, no_specular(S.shade[node_id]))) { cnt.elided++; pre_lit = false; } // (as if shadowed: the sample's term is 0 either way)
+            if (!STATS && NR_ELIDE_DARK && light_is_dark(ldir, is.n, ray.d, no_specular(S.shade[node_id]))) { if (count_me) cnt.elided++; pre_lit = false; } // (as if shadowed: the sample's term is 0 either way)
             else {
             // kFeatPark: the hit's record and the ray wait in LDS while the shadow ray is traced (the same bits come back)
             if ((FEAT & kFeatPark) && (FEAT & kFeatAlphaShadow)) {
