@@ -126,7 +126,7 @@ def roofline_block(pk, tst, W, owned_rows, scene_bytes, pmc, pmc_source, tile_co
         lim = {"longest_tile_cycles": int(tile_costs.max_cycles), "sum_tile_cycles": int(tile_costs.sum_cycles), "wave_tiles": int(tile_costs.tiles),
                "resident_waves": int(tile_costs.resident_waves), "longest_tile_frac": round(longest / t, 4),
                "wave_throughput_frac": round(through / t, 4),
-               "source": "nrays_get_tile_costs: s_memtime cycles of every wave tile of this camera's cost-recording frame"}
+               "source": "nrays_get_tile_costs: s_memtime cycles of every wave tile of this camera's cost-recording frame (a tile the cost-ordered lists split: by part)"}
         lim["name"] = "latency/longest-tile" if longest >= through else "throughput/wave-cycles"
         lim["frac"] = round(max(longest, through) / t, 4)
         r["limiter"] = lim

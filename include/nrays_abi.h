@@ -250,8 +250,8 @@ int nrays_get_primary_kernel_stats(NraysScene* scene, NraysStats* out_stats);
  * before its LONGEST tile does (a pixel's chain of dependent traversals), nor before sum / resident_waves cycles have passed. */
 typedef struct NraysTileCosts {
     uint64_t tiles;          /* wave tiles recorded */
-    uint64_t sum_cycles;     /* shader cycles (s_memtime) over all of them */
-    uint64_t max_cycles;     /* the longest tile */
+    uint64_t sum_cycles;     /* shader cycles (s_memtime) the waves spend on them (every part of a tile the cost-ordered lists split counted) */
+    uint64_t max_cycles;     /* the longest unit the schedule deals: a tile, or ONE PART of a split tile (light-parallel / pixel-split parts) */
     uint64_t resident_waves; /* waves of the persistent grid that rendered the frame */
 } NraysTileCosts;
 int nrays_get_tile_costs(NraysScene* scene, NraysTileCosts* out);

@@ -1222,7 +1222,7 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
     HIP_TRY(hipMemsetAsync(sc->d_wave_times, 0, (size_t)kMaxGrid * (kBlock / 64) * 8 * sizeof(uint32_t), stream));
     R.wave_times = sc->d_wave_times; sc->dbg_grid = grid_primary; R.dbg_mode = getenv("NRAYS_DEBUG_WAVE_WORK") ? (uint32_t)atoi(getenv("NRAYS_DEBUG_WAVE_WORK")) : 0u;
 #endif
-    if (R.tile_cost) { sc->cost_tiles = lane_log2 ? win_units : win_units * 4u; sc->cost_grid = grid_primary; }
+    if (R.tile_cost) { sc->cost_tiles = lane_log2 ? win_units : win_units * 4u; sc->cost_grid = grid_primary; sc->cost_split_lsl = R.light_lsl; }
     bool first_primary = true;
     for (uint32_t s0 = 0; s0 < p->ray_per_pixel; s0 += batch) {
         R.sample_begin = s0; R.sample_end = std::min<uint32_t>(p->ray_per_pixel, s0 + batch);
@@ -1606,7 +1606,20 @@ int nrays_get_tile_costs(NraysScene* sc, NraysTileCosts* out) {
     HIP_TRY(hipStreamSynchronize(sc->last_stream));
     std::vector<uint32_t> c(sc->cost_tiles);
     HIP_TRY(hipMemcpy(c.data(), sc->d_tile_cost, c.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    for (uint32_t v : c) { out->sum_cycles += (uint64_t)v * 16u; out->max_cycles = std::max<uint64_t>(out->max_cycles, (uint64_t)v * 16u); }
+    // The unit the schedule deals is a wave tile — or ONE PART of a tile the cost-ordered lists split (k_tile_order: tiles at or above light_split_factor x the frame's work per
+    // resident wave; a part's cycles were recorded x 2^lsl, or x 3 for the pixel-split tiles of one-light frames).  max_cycles is the longest such unit, sum_cycles what the
+    // waves spend: every part of a split tile counted.
+    const uint32_t lsl = sc->cost_split_lsl;
+    const bool multi = (sc->features & kFeatMultiSample) != 0;
+    uint64_t rec_sum = 0;
+    for (uint32_t v : c) rec_sum += v;
+    const uint64_t waves = std::max<uint64_t>(1, (uint64_t)sc->cost_grid * (kBlock / 64));
+    const double thr = !lsl || sc->light_split_factor == 0.0f ? 1e300 : (sc->light_split_factor < 0.0f ? 0.0 : (double)sc->light_split_factor * (double)rec_sum / (double)waves);
+    for (uint32_t v : c) {
+        uint64_t unit = v, n = 1;
+        if (lsl && v != 0u && (double)v >= thr) { unit = multi ? (uint64_t)(v >> lsl) : (uint64_t)(v / 3u); n = 1ull << lsl; }
+        out->sum_cycles += unit * n * 16u; out->max_cycles = std::max<uint64_t>(out->max_cycles, unit * 16u);
+    }
     out->tiles = c.size(); out->resident_waves = (uint64_t)sc->cost_grid * (kBlock / 64);
     return NRAYS_OK;
 }

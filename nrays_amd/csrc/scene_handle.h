@@ -54,7 +54,7 @@ struct NraysScene {
     uint32_t light_lsl = 0; float light_split_factor = 1.0f; uint32_t* d_order_len = nullptr;
     const float* d_seed_boxes = nullptr; uint32_t seed_boxes = 0; bool seed_enabled = true; uint32_t seed_rays = 1; // k_seed_costs: first guess of a cold camera's tile costs (NRAYS_COST_SEED=0: none)
     uint64_t cost_key = 0; bool cost_valid = false;
-    uint32_t cost_tiles = 0, cost_grid = 0; // wave tiles / workgroups of the frame that recorded d_tile_cost last (nrays_get_tile_costs)
+    uint32_t cost_tiles = 0, cost_grid = 0, cost_split_lsl = 0; // wave tiles / workgroups / log2 of a split tile's parts of the frame that recorded d_tile_cost last (nrays_get_tile_costs)
     // analytic scenes (workgroup lists): costs are recorded on the first frame of a camera, sorted once on the second, and
     // the order is then reused as long as the camera stays (the scene of a handle never changes)
     uint64_t cost_cam = 0, order_key = 0, order_cam = 0; bool order_valid = false; uint32_t order_age = 0;
