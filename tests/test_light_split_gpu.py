@@ -1,6 +1,6 @@
 """Light-parallel wave tiles (DRender::light_lsl, k_tile_order): in multi-light mesh frames the tiles above a cost threshold are
 rendered as 2^k parts, 2^k lanes per pixel, one light per lane in the shadow phase, the per-light sums folded in light order by
-`__shfl` — scheduling only: the frame and the ray counts must be IDENTICAL to the one-lane-per-pixel render, whatever is split
+`__shfl`; in ONE-light alpha-mapped mesh frames the same parts are 64 >> k pixels whose lanes trace the same rays — scheduling only: the frame and the ray counts must be IDENTICAL to the one-lane-per-pixel render, whatever is split
 (reference: the light loop of src/phong_material.rs:106-147)."""
 import ctypes as C
 
@@ -30,7 +30,7 @@ def _frames(make, w, h, n, **kw):
     return sc, p, out
 
 
-@pytest.mark.parametrize("lights", [8, 5, 3, 2])
+@pytest.mark.parametrize("lights", [8, 5, 3, 2, 1])  # (1: the pixel-split parts of one-light alpha-mapped frames, NR_PIXEL_SPLIT)
 def test_split_tiles_do_not_change_a_pixel(gpu, monkeypatch, lights):
     from tools import standins
     make = lambda: standins.sponza_scene(detail=0.2, n_lights=lights)
