@@ -13,7 +13,7 @@
 #define NR_SAH_BINS 32 // 16 -> 32: hairball -1 %, sponza -0.4 %, same build time
 #endif
 #ifndef NR_PRIM_COST
-#define NR_PRIM_COST 0.5f // re-tuned with the prefetching leaf loop (0.7 before): sponza -0.8 %, hairball -4 %
+#define NR_PRIM_COST 1.0f // round 5, three waves per SIMD and the frames bound by their sum of tile cycles (0.5 before, 0.7 before that; hair-like meshes have their own): with NR_PRESPLIT_MINGAIN 1.0 sponza 1.052 -> 1.039 ms, 8 lights 2.61 -> 2.56 (3.7 / 4.0 instead of 4.9 triangle tests per ray; profiles/r05_build_knobs_sweep.log)
 #endif
 
 #ifdef __HIPCC__

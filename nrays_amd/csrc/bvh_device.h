@@ -32,8 +32,8 @@ struct DeviceBlas {
 
 struct DeviceBuildOptions {
     int max_leaf = 8;
-    float prim_cost = 0.5f, prim_cost_hairy = 0.7f;
-    double budget = 1.0, budget_hairy = 5.0, min_gain = 0.5, min_gain_hairy = 0.05, hairy_emptiness = 0.9;
+    float prim_cost = 1.0f, prim_cost_hairy = 0.7f;
+    double budget = 1.0, budget_hairy = 5.0, min_gain = 1.0, min_gain_hairy = 0.02, hairy_emptiness = 0.9;
     bool presplit = true;
     int debug_cap_div = 1;    // NRAYS_DEBUG_BUILD_CAPS=n (tests): the builder's internal lists get 1 / n of their capacity, so that their overflow path — an error the caller answers with the host builder — runs
     size_t node_tail = 16384; // spare node slots behind the BLAS: a scene with ONE device-built BLAS adopts its arrays as they are (no second copy of GBs)

@@ -152,7 +152,7 @@ struct Blas {
 #define NR_PRESPLIT_BUDGET 1.0  // at most this many extra references per triangle on average
 #endif
 #ifndef NR_PRESPLIT_MINGAIN
-#define NR_PRESPLIT_MINGAIN 0.5 // a piece is split while its empty box area exceeds this fraction of the average box area
+#define NR_PRESPLIT_MINGAIN 1.0 // a piece is split while its empty box area exceeds this fraction of the average box area (round 5: 0.5 -> 1.0, see NR_PRIM_COST)
 #endif
 // refs_box / refs_tri: one entry per reference (initially one per triangle), grown in place.  Candidates are pieces
 //   (a) whose box is at least NR_PRESPLIT_EMPTY empty (1 - 2 area / half box area: thin diagonal primitives; a large
