@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Where a kernel's scratch (spill) accesses sit: instructions and scratch loads / stores of one k_primary instantiation by loop depth (LLVM's "Depth=" annotations
-in the assembly), and every block of depth >= 5 — the node loop, the triangle loop — with its instruction mix.  CPU only (hipcc -S, ~1.5 min).
+in the assembly), and every block of depth >= 5 — the node loop, the triangle loop — with its instruction mix.  CPU only (hipcc -S of every group of
+primary_inst.hip, ~30 s; REBUILD=1 refreshes /tmp/nrays_isa.s).
 
   python tools/isa_scratch.py "k_primaryILb0ELi2ELb1ELi0E" ["k_primaryILb0ELi214ELb1ELi3E" ...]      (mangled-name fragments)
 """
@@ -10,8 +11,14 @@ import __graft_entry__ as g
 
 asm = "/tmp/nrays_isa.s"
 if not os.path.exists(asm) or os.environ.get("REBUILD"):
+    from concurrent.futures import ThreadPoolExecutor
     flags = [f for f in g.HIP_FLAGS if f != "-fPIC"]
-    subprocess.check_call(["/opt/rocm/bin/hipcc"] + flags + ["-DNR_ONLY_MESH", "-S", "--cuda-device-only", "-o", asm, os.path.join(g.CSRC, "nrays_hip.hip")], stderr=subprocess.DEVNULL)
+    parts = ["/tmp/nrays_isa_g%d.s" % k for k in range(g.PRIMARY_GROUPS)]
+    with ThreadPoolExecutor(max_workers=os.cpu_count() or 4) as ex:
+        list(ex.map(lambda k: subprocess.check_call(["/opt/rocm/bin/hipcc"] + flags + ["-DNR_PRIMARY_GROUP=%d" % k, "-S", "--cuda-device-only", "-o", parts[k],
+                                                     os.path.join(g.CSRC, "primary_inst.hip")], stderr=subprocess.DEVNULL), range(g.PRIMARY_GROUPS)))
+    with open(asm, "w") as f:
+        for q in parts: f.write(open(q).read() + "\n")
 text = open(asm).read().split("\n")
 for frag in sys.argv[1:] or ["k_primaryILb0ELi2ELb1ELi0E"]:
     start = next(i for i, l in enumerate(text) if l.startswith("_Z") and frag in l.split(":")[0] and ":" in l)

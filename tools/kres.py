@@ -28,12 +28,23 @@ def main():
         else:
             extra.append(a)
     os.makedirs(os.path.dirname(out), exist_ok=True)
-    srcs = [os.path.join(g.CSRC, s) for s in g.HIP_SOURCES]
-    cmd = ["/opt/rocm/bin/hipcc"] + g.HIP_FLAGS + extra + ["-Rpass-analysis=kernel-resource-usage", "-shared", "-o", out] + srcs + g.HIP_LINK
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-    if r.returncode != 0:
-        print(r.stdout[-4000:])
-        raise SystemExit(r.returncode)
+    # the library's translation units (k_primary's permutations: one unit per group of primary_inst.hip), compiled side by side with the remarks on
+    from concurrent.futures import ThreadPoolExecutor
+    objdir = out + ".obj"
+    os.makedirs(objdir, exist_ok=True)
+    units = [("primary_inst.hip", "g%d.o" % k, ["-DNR_PRIMARY_GROUP=%d" % k]) for k in range(g.PRIMARY_GROUPS)] + [(s_, s_ + ".o", []) for s_ in g.HIP_SOURCES]
+    def compile_unit(u):
+        return subprocess.run(["/opt/rocm/bin/hipcc"] + g.HIP_FLAGS + extra + u[2] + ["-Rpass-analysis=kernel-resource-usage", "-c", "-o", os.path.join(objdir, u[1]),
+                               os.path.join(g.CSRC, u[0])], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    with ThreadPoolExecutor(max_workers=os.cpu_count() or 4) as ex:
+        rs = list(ex.map(compile_unit, units))
+    for r in rs:
+        if r.returncode != 0:
+            print(r.stdout[-4000:])
+            raise SystemExit(r.returncode)
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + [os.path.join(objdir, u[1]) for u in units] + g.HIP_LINK)
+    class R_: pass
+    r = R_(); r.stdout = "\n".join(x.stdout for x in rs)
     rows, cur = [], None
     for line in r.stdout.splitlines():
         m = re.search(r"remark: (?:Function Name|Name): (\S+)", line) or re.search(r"Function Name: (\S+)", line) or re.search(r" Name: (\S+) \[", line)
