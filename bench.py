@@ -18,7 +18,7 @@ At N = 1 the line also carries
                  wave, from the library's per-tile cycle counts), dram_frac, valu_active_frac, wave_wait_frac,
                  fp64_issue_frac, l2_gbs, compulsory_bytes — from rocprofv3 --pmc passes run live by this script
                  (traffic_source says whether the counters are live or replayed from profiles/);
-  scene_build_s, cold_frame_ms, moving_camera_ms_per_frame   what a caller pays besides the resting-camera steady state
+  value_cold, value_moving, scene_build_s, cold_frame_ms, moving_camera_ms_per_frame   what a caller gets outside the resting-camera steady state
   two_frames_in_flight_ms_per_frame   two handles / streams / frame buffers alternating (information; never `value`)
                  the contract's loop times (the reference's only caller renders each camera ONCE);
   value_traced   the rate on the rays that went through a BVT query (wave tiles outside the scene's screen bounds are
@@ -297,7 +297,19 @@ def single_gpu_measure(name, W, H, steps, warmup, args, pmc=True, moving=True):
     del warm_scene
     # (2) what a drop-in scene::render delivers for ONE render of a camera (loader3d.rs:67-93 renders each camera once):
     # Scene::new -> nrays_scene_create (flatten, BVH build, upload), then the FIRST frame of the fresh handle — no cost
-    # history (image-order work lists), cost recording on, raygen tables built, per-handle buffers allocated
+    # history (mesh scenes: k_seed_costs' guess; analytic scenes: image-order work lists), cost recording on.  Median over
+    # several fresh handles (the frame is host-synchronised: launch latency + GPU time + wake-up).
+    cold_walls, cold_gpu = [], []
+    for _ in range(3):
+        cs, _, _ = load_workload(name)
+        ch = cs.device_handle()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        render_on(ch, p)
+        torch.cuda.synchronize()
+        cold_walls.append((time.perf_counter() - t0) * 1e3)
+        cold_gpu.append(nr.get_stats(cs).kernel_ms_total)
+        del cs
     scene, cam, desc = load_workload(name)
     t0 = time.perf_counter()
     handle = scene.device_handle()
@@ -309,6 +321,8 @@ def single_gpu_measure(name, W, H, steps, warmup, args, pmc=True, moving=True):
         render_on(handle, p)
         torch.cuda.synchronize()
         first.append((time.perf_counter() - t0) * 1e3)
+    cold_walls.append(first[0])
+    cold_ms = sorted(cold_walls)[len(cold_walls) // 2]
 
     render_on(handle, p, True)
     st = nr.get_stats(scene)
@@ -334,6 +348,14 @@ def single_gpu_measure(name, W, H, steps, warmup, args, pmc=True, moving=True):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     tst = nr.get_stats(scene)
+    # the same resting frame, host-synchronised one at a time: what the cold frame's wall time has to be compared with
+    sync_walls = []
+    for _ in range(10):
+        t0 = time.perf_counter()
+        render_on(handle, p)
+        torch.cuda.synchronize()
+        sync_walls.append((time.perf_counter() - t0) * 1e3)
+    nr.get_stats(scene)
     plain = st  # the instrumented frame's counters: rays_primary_traced (what reached a BVT query) is only counted there
     # shadow rays whose result is multiplied by exactly 0 (light samples behind the surface; hits that contribute nothing of their own: fully transparent
     # points, perfect mirrors): counted in rays_shadow — the reference traces them — but not traced by the plain (timed) frames; not part of the traced rate
@@ -350,21 +372,45 @@ def single_gpu_measure(name, W, H, steps, warmup, args, pmc=True, moving=True):
            "value_traced": round((plain.rays_traced() - elided) * steps / dt / 1e6, 3),
            "scene_build_s": round(scene_build_s, 4),
            "scene_build_note": "nrays_scene_create as the caller sees it; BLASes of >= 2 000 triangles are built on the GPU (nrays_amd/csrc/bvh_device.hip), smaller ones and the TLASes on the host",
-           "cold_frame_ms": round(first[0], 4), "second_frame_ms": round(first[1], 4), "third_frame_ms": round(first[2], 4),
-           "cold_frame_note": "fresh handle in a warm process (kernels loaded): first scene::render of a camera — no cost history, cost "
-                              "recording, raygen tables, per-handle buffer allocation; host-synchronised wall time"}
+           "cold_frame_ms": round(cold_ms, 4), "cold_frame_gpu_ms": round(sorted(cold_gpu)[len(cold_gpu) // 2], 4),
+           "second_frame_ms": round(first[1], 4), "third_frame_ms": round(first[2], 4),
+           "steady_frame_sync_ms": round(sorted(sync_walls)[len(sync_walls) // 2], 4),
+           # the rate a caller gets who renders every camera ONCE (the reference's only call pattern): the frame's rays over the host-synchronised
+           # wall time of the first frame of a fresh handle (steady_frame_sync_ms is the resting frame measured the same way)
+           "value_cold": round(st.total_rays() / (cold_ms * 1e-3) / 1e6, 3),
+           "cold_frame_note": "fresh handle in a warm process (kernels loaded), median of %d: first scene::render of a camera — no cost history "
+                              "(mesh scenes: guessed order; analytic scenes: image-order lists), cost recording; host-synchronised wall time" % len(cold_walls)}
     if moving and cam.get("spp", 1) == 1:
-        # a camera that moves every frame (eye shifted by 1e-3 of its distance per frame): cost recording + re-sorting stay on
+        # a camera that moves every frame (eye shifted by 1e-3 of its distance per frame): the library re-sorts mesh frames from the previous
+        # frame's costs, analytic frames keep a nearby camera's order for a few frames; frames pipelined like the steady loop
         import numpy as np
         eye0 = np.array(cam["eye"], dtype=np.float64); at = np.array(cam["at"], dtype=np.float64)
         frames = max(10, min(steps, 40))
         params = [camera_params(dict(cam, eye=tuple(eye0 + (k + 1) * 1e-3 * np.linalg.norm(eye0 - at) * np.array([1.0, 0.0, 0.0]))), W, H) for k in range(frames)]
+        best = None
+        for _ in range(2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for q in params:
+                render_on(handle, q)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / frames * 1e3
+            best = ms if best is None else min(best, ms)
+        res["moving_camera_ms_per_frame"] = round(best, 5)
+        # (the rays of the moving frames differ from the resting frame's by a fraction of a percent: the resting frame's count is used)
+        res["value_moving"] = round(st.total_rays() / (best * 1e-3) / 1e6, 3)
+        # the last camera of the path at rest on a handle of its own: what that frame costs when nothing has to be learnt about it
+        rs, _, _ = load_workload(name)
+        rh = rs.device_handle()
+        for _ in range(6):
+            render_on(rh, params[-1])
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for q in params:
-            render_on(handle, q)
+        for _ in range(20):
+            render_on(rh, params[-1])
         torch.cuda.synchronize()
-        res["moving_camera_ms_per_frame"] = round((time.perf_counter() - t0) / frames * 1e3, 5)
+        res["moving_path_last_camera_at_rest_ms"] = round((time.perf_counter() - t0) / 20 * 1e3, 5)
+        del rs
     if moving and cam.get("spp", 1) == 1:
         # two frames in flight: a second handle of the same scene, a second stream and a second frame buffer, renders alternating —
         # what a caller who double-buffers an animation gets (the tail of one launch overlaps the next one; a handle serialises its own
@@ -473,9 +519,13 @@ def run_single(args):
                    "rays_per_frame": m["rays_per_frame"], "rays_traced_per_frame": m["rays_traced_per_frame"],
                    "steady_state": m["steady_state"]},
         "value_traced": m["value_traced"],
-        "scene_build_s": m["scene_build_s"], "cold_frame_ms": m["cold_frame_ms"], "second_frame_ms": m["second_frame_ms"],
+        # the other two regimes a caller can be in, as rates of the same rays: one render per camera on a fresh handle
+        # (host-synchronised: compare with steady_frame_sync_ms, not with ms_per_step), and a camera that moves every frame (pipelined)
+        "value_cold": m["value_cold"], "value_moving": m.get("value_moving"),
+        "scene_build_s": m["scene_build_s"], "cold_frame_ms": m["cold_frame_ms"], "cold_frame_gpu_ms": m["cold_frame_gpu_ms"],
+        "steady_frame_sync_ms": m["steady_frame_sync_ms"], "second_frame_ms": m["second_frame_ms"],
         "third_frame_ms": m["third_frame_ms"], "cold_frame_note": m["cold_frame_note"],
-        "moving_camera_ms_per_frame": m.get("moving_camera_ms_per_frame"),
+        "moving_camera_ms_per_frame": m.get("moving_camera_ms_per_frame"), "moving_path_last_camera_at_rest_ms": m.get("moving_path_last_camera_at_rest_ms"),
         "two_frames_in_flight_ms_per_frame": m.get("two_frames_in_flight_ms_per_frame"),
         "two_frames_in_flight_identical": m.get("two_frames_in_flight_identical"),
         "roofline": m["roofline"],

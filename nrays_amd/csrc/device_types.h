@@ -140,7 +140,9 @@ struct DeviceCounters {
     unsigned int overflow;  // set when a continuation queue ran out of capacity
     unsigned int max_depth; // deepest trace depth reached (= number of continuation generations)
     unsigned int max_chain_nodes; // instrumented: most AABB tests spent on one pixel's chain
-    unsigned int shadow_elided; // shadow rays counted in rays_shadow but not traced: hits on fully transparent / perfectly mirroring points contribute nothing of their own (trace_device.h: shade_hit)
+    unsigned int pad0;
+    unsigned long long shadow_elided; // shadow rays counted in rays_shadow but not traced (64 bits like rays_shadow, which contains them: a 4K frame with 256 samples and 8 lights passes 2^32): light samples
+                                      // behind the surface, hits on fully transparent / perfectly mirroring points (trace_device.h: light_is_dark, shade_hit)
     unsigned long long dbg2[8];   // tuning builds (NR_PHASE_TIMING): wave cycles outside the queries — dequeue wait, raygen + root test, hit reconstruction + gates, shadow-ray set-up, material, weights + continuation, pixel write
     unsigned long long dbg[8];    // tuning builds (NR_PHASE_TIMING): wave / lane iteration counts of the node loops and triangle leaves, cycles per query class, wave-uniform node iterations
 };
@@ -182,6 +184,8 @@ struct DScene {
     uint32_t num_lights;
     float background[3];
     uint32_t incoherent;          // some mesh is hair-like (kInstIncoherent): traverse() ends node phases by quorum
+    uint32_t no_elide;            // some light / material / RGBA32F texel of the scene is not finite (or a shininess is negative): x * 0 is then not 0 for every x the
+                                  // reference multiplies, so NO shadow ray or Phong evaluation is skipped (light_is_dark(), shade_hit()); nrays_scene_create decides
     // Small analytic scenes (no meshes; all records below within kLdsSceneBytes): one packed copy of nodes, instances,
     // links, shading records, node AABBs, lights and plane lists, which the kFeatLdsScene kernels stage into LDS once per
     // workgroup — a dependent record fetch then costs an LDS access instead of a trip through the vector memory path.
@@ -218,14 +222,10 @@ struct DRender {
     uint32_t lead_wgs;
     uint32_t lead_entries; // how many entries the lead workgroups own (lead_wgs * 1..4)
     double window_width;
+    double inv_width, inv_height; // RN(1 / width), RN(1 / height): the PLAIN kernels' raygen divides by them exactly (trace_device.h: generate_primary)
     double eye[3];
     double m[16];                // (P V)^-1 column-major
     unsigned long long seed;
-    // Without AA jitter the primary ray of pixel (i, j) only needs M[:,0] * dx_i and M[:,1] * dy_j: tabulated
-    // once per camera by k_raygen_tables (4 f64 per column / row, same operations as the in-kernel path, so
-    // bit-identical); null when window_width != 0.
-    const double* col_tab;
-    const double* row_tab;
     // Mesh scenes (dynamic dequeue): per-wave-tile cost of this frame (written) and the wave tiles in
     // descending order of the previous frame's cost (read; null = image order).  Scheduling only.
     uint32_t* tile_cost;
@@ -243,6 +243,8 @@ struct DRender {
     uint32_t light_lsl;
 };
 constexpr uint32_t kEntrySplit = 0x80000000u, kEntryTileMask = 0x0fffffffu;
+// A recorded tile cost (DRender::tile_cost, 16-cycle units): bit 31 = the tile ran as light-parallel / pixel-split parts and the value is its most expensive part's, scaled to the tile.
+constexpr uint32_t kCostSplit = 0x80000000u, kCostMask = 0x7fffffffu;
 
 // Kernel permutations by scene content (decided once per scene on the host): a scene only pays, in
 // registers and instructions, for the code paths it can reach.

@@ -1,8 +1,6 @@
 // nrays_hip.hip — gfx950 kernels and the C-ABI entry points of include/nrays_abi.h.
 //
 // Launch structure of one nrays_render (replaces scene::render, src/scene.rs:29-116):
-//   k_raygen_tables  only when the camera or the resolution of a jitter-free frame changed: per-column / per-row
-//               products of the unprojection (a few microseconds, cached on the scene handle).
 //   k_tile_order     mesh scenes, from the second frame of a geometry on: wave tiles sorted by the previous frame's
 //               per-tile cost (8 LDS counting sorts), so that the deep chains start first.
 //   k_primary   persistent grid; one lane per pixel of an 8x8 wave tile, looping over the AA samples of the batch:
@@ -151,8 +149,10 @@ __device__ __forceinline__ uint32_t cost_bucket(uint32_t c) {
 // resident wave (its list's sum x 8 / waves: the lists are uniform samples of the image) would sit on the frame's critical path —
 // it enters the list as 2^split_lsl entries (its parts, DRender::light_lsl), each priced at a third of the tile.  split_factor < 0
 // splits every tile (tests).  order_len[x] receives the list's length.
-__global__ void __launch_bounds__(1024) k_tile_order(const uint32_t* __restrict__ cost, uint32_t* __restrict__ order, uint32_t n, unsigned long long* stats,
-                                                     uint32_t split_lsl, float split_factor, uint32_t waves, uint32_t* __restrict__ order_len) {
+// clear != 0: every cost is zeroed after its last read here — the frame that follows records into split entries by atomicMax, and a memset of its own
+// would be one more launch between this kernel and k_primary.
+__global__ void __launch_bounds__(1024) k_tile_order(uint32_t* __restrict__ cost, uint32_t* __restrict__ order, uint32_t n, unsigned long long* stats,
+                                                     uint32_t split_lsl, float split_factor, uint32_t waves, uint32_t* __restrict__ order_len, uint32_t clear, float split_hyst) {
     __shared__ uint32_t hist[256];
     __shared__ unsigned long long wg_sum;
     __shared__ uint32_t wg_max, wg_total;
@@ -161,19 +161,21 @@ __global__ void __launch_bounds__(1024) k_tile_order(const uint32_t* __restrict_
     if (threadIdx.x == 0u) { wg_sum = 0ULL; wg_max = 0u; wg_total = 0u; }
     __syncthreads();
     unsigned long long my_sum = 0ULL; uint32_t my_max = 0u;
-    for (uint32_t i = x + 8u * threadIdx.x; i < n; i += 8u * 1024u) { const uint32_t c = cost[i]; my_sum += c; my_max = c > my_max ? c : my_max; }
-    if (stats || split_lsl) { // stats[0] = sum of all tile costs, stats[1] = the largest one (both in the 16-cycle units of the cost array)
+    for (uint32_t i = x + 8u * threadIdx.x; i < n; i += 8u * 1024u) { const uint32_t c = cost[i] & kCostMask; my_sum += c; my_max = c > my_max ? c : my_max; }
+    if (stats || split_lsl) { // stats[2x] = sum of list x's tile costs, stats[2x + 1] = its largest one (both in the 16-cycle units of the cost array)
         if (my_sum) atomicAdd(&wg_sum, my_sum);
         if (my_max) atomicMax(&wg_max, my_max);
     }
     __syncthreads();
-    if (stats && threadIdx.x == 0u) { atomicAdd(&stats[0], wg_sum); atomicMax(&stats[1], (unsigned long long)wg_max); }
-    const unsigned long long thr = !split_lsl ? ~0ULL : (split_factor < 0.0f ? 0ULL : (unsigned long long)(split_factor * (double)(wg_sum * 8ULL) / (double)(waves ? waves : 1u)));
+    if (stats && threadIdx.x == 0u) { stats[2u * x] = wg_sum; stats[2u * x + 1u] = (unsigned long long)wg_max; } // per list: no memset before the launch, the host adds them up
+    const double per_wave = (double)(wg_sum * 8ULL) / (double)(waves ? waves : 1u);
+    const unsigned long long thr = !split_lsl ? ~0ULL : (split_factor < 0.0f ? 0ULL : (unsigned long long)(split_factor * per_wave));
+    const unsigned long long thr_keep = !split_lsl ? ~0ULL : (split_factor < 0.0f ? 0ULL : (unsigned long long)(split_factor * split_hyst * per_wave)); // a tile that ran in parts stays split down to here
     const uint32_t parts = 1u << split_lsl;
-    auto heavy = [&](uint32_t c) { return split_lsl != 0u && (unsigned long long)c >= thr && (split_factor < 0.0f || c != 0u); };
+    auto heavy = [&](uint32_t rec) { const uint32_t c = rec & kCostMask; return split_lsl != 0u && (unsigned long long)c >= ((rec & kCostSplit) ? thr_keep : thr) && (split_factor < 0.0f || c != 0u); };
     for (uint32_t i = x + 8u * threadIdx.x; i < n; i += 8u * 1024u) {
-        const uint32_t c = cost[i];
-        if (heavy(c)) atomicAdd(&hist[cost_bucket(c / 3u)], parts); else atomicAdd(&hist[cost_bucket(c)], 1u);
+        const uint32_t rec = cost[i], c = rec & kCostMask;
+        if (heavy(rec)) atomicAdd(&hist[cost_bucket(c / 3u)], parts); else atomicAdd(&hist[cost_bucket(c)], 1u);
     }
     __syncthreads();
     if (threadIdx.x == 0) { // exclusive prefix, most expensive bucket first
@@ -183,11 +185,12 @@ __global__ void __launch_bounds__(1024) k_tile_order(const uint32_t* __restrict_
     }
     __syncthreads();
     for (uint32_t i = x + 8u * threadIdx.x; i < n; i += 8u * 1024u) {
-        const uint32_t c = cost[i];
-        if (heavy(c)) {
+        const uint32_t rec = cost[i], c = rec & kCostMask;
+        if (heavy(rec)) {
             const uint32_t at = atomicAdd(&hist[cost_bucket(c / 3u)], parts);
             for (uint32_t s = 0; s < parts; ++s) order[8u * (at + s) + x] = i | (s << 28) | kEntrySplit;
         } else order[8u * atomicAdd(&hist[cost_bucket(c)], 1u) + x] = i;
+        if (clear) cost[i] = 0u;
     }
     if (order_len && threadIdx.x == 0u) order_len[x] = wg_total;
 }
@@ -288,6 +291,52 @@ static ScreenBounds screen_bounds(const HostScene& h, const NraysRenderParams* p
     return r;
 }
 
+// What a cost order recorded for one camera is worth for another: the larger of (a) the angle between the two cameras' rays through each
+// corner of the frame and (b) the parallax of the nearest geometry — |eye shift| over the distance from the eye to the scene's bounding box
+// (at least a twentieth of its diagonal: a camera inside the scene) — both in pixels of the frame.  Tile costs vary over blocks of pixels, so
+// an order stays useful while the view has shifted by less than a block (kNearPixels).  Scheduling only.
+constexpr double kNearPixels = 16.0;
+static CamSnap cam_snapshot(const HostScene& h, const NraysRenderParams* p) {
+    CamSnap c; c.valid = false;
+    const double* M = p->inv_proj_view;
+    for (int a = 0; a < 3; ++a) c.eye[a] = p->camera_eye[a];
+    for (int k = 0; k < 4; ++k) {
+        const double dx = (k & 1) ? 1.0 : -1.0, dy = (k & 2) ? 1.0 : -1.0;
+        double hh[4];
+        for (int r = 0; r < 4; ++r) hh[r] = M[r] * dx + M[4 + r] * dy - M[8 + r] + M[12 + r];
+        double d[3], n = 0.0;
+        for (int a = 0; a < 3; ++a) { d[a] = hh[a] / hh[3] - c.eye[a]; n += d[a] * d[a]; }
+        n = std::sqrt(n);
+        if (!(n > 0.0) || !std::isfinite(n)) return c;
+        for (int a = 0; a < 3; ++a) c.dir[k][a] = d[a] / n;
+    }
+    // angle of one pixel: the frame's diagonal chord over its diagonal in pixels
+    double chord = 0.0;
+    for (int a = 0; a < 3; ++a) chord += (c.dir[3][a] - c.dir[0][a]) * (c.dir[3][a] - c.dir[0][a]);
+    c.pix_angle = std::sqrt(chord) / std::sqrt((double)p->width * p->width + (double)p->height * p->height);
+    // distance to the nearest point of the bounded part of the scene
+    double diag = 0.0, dist = 0.0; bool box = true;
+    for (int a = 0; a < 3; ++a) {
+        const double mn = h.bounds_mn[a], mx = h.bounds_mx[a];
+        if (!(mn <= mx) || !std::isfinite(mn) || !std::isfinite(mx)) { box = false; break; }
+        diag += (mx - mn) * (mx - mn);
+        const double o = c.eye[a] < mn ? mn - c.eye[a] : (c.eye[a] > mx ? c.eye[a] - mx : 0.0);
+        dist += o * o;
+    }
+    c.depth = box ? std::max(std::sqrt(dist), 0.05 * std::sqrt(diag)) : 1.0;
+    c.valid = c.pix_angle > 0.0 && std::isfinite(c.pix_angle) && c.depth > 0.0;
+    return c;
+}
+static double cam_shift_px(const CamSnap& a, const CamSnap& b) {
+    if (!a.valid || !b.valid) return INFINITY;
+    const double pa = std::min(a.pix_angle, b.pix_angle);
+    double rot = 0.0, tr = 0.0;
+    for (int k = 0; k < 4; ++k) { double q = 0.0; for (int x = 0; x < 3; ++x) q += (a.dir[k][x] - b.dir[k][x]) * (a.dir[k][x] - b.dir[k][x]); rot = std::max(rot, std::sqrt(q)); }
+    for (int x = 0; x < 3; ++x) tr += (a.eye[x] - b.eye[x]) * (a.eye[x] - b.eye[x]);
+    const double v = std::max(rot, std::sqrt(tr) / std::min(a.depth, b.depth)) / pa;
+    return std::isfinite(v) ? v : INFINITY;
+}
+
 // Image::to_png quantisation (src/image.rs:66-76) of a finished frame: c * 255, clamped to [0, 255], truncated; NaN and
 // negatives -> 0 (Rust's saturating `as u8`).  Same f32 operations as the host front-end's quantize_rgb8 (png_codec.cpp).
 __global__ void k_quantize_rgb8(const float* __restrict__ rgb, uint8_t* __restrict__ out, size_t n) {
@@ -297,21 +346,6 @@ __global__ void k_quantize_rgb8(const float* __restrict__ rgb, uint8_t* __restri
     v = (v > 0.0f) ? v : 0.0f;
     v = v > 255.0f ? 255.0f : v;
     out[i] = (uint8_t)(uint32_t)v;
-}
-
-// Per-column / per-row raygen products for jitter-free cameras (see DRender::col_tab): thread t < width
-// writes M[:,0] * dx_t, thread width + t writes M[:,1] * dy_t, with exactly the operations of
-// generate_primary (scene.rs:81-83), so the tabulated path is bit-identical to the direct one.
-__global__ void k_raygen_tables(double* col_tab, double* row_tab, uint32_t width, uint32_t height, DRender R) {
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < width) {
-        double dx = ((double)t / (double)width - 0.5) * 2.0;
-        for (int r = 0; r < 4; ++r) col_tab[4 * (size_t)t + r] = R.m[r] * dx;
-    } else if (t < width + height) {
-        uint32_t j = t - width;
-        double dy = -((double)j / (double)height - 0.5) * 2.0;
-        for (int r = 0; r < 4; ++r) row_tab[4 * (size_t)j + r] = R.m[4 + r] * dy;
-    }
 }
 
 __global__ void k_resolve(float* out, size_t n, float spp) { // pxs.push(tot_c / ray_per_pixel as f32), scene.rs:94
@@ -434,7 +468,7 @@ static void launch_primary(bool instrumented, int features, bool noxform, bool p
     };
     if (instrumented) { launch(true, kFeatAll, false, 0); return; }
     // plain frames: no RNG keys, one sample per pixel
-    const bool plain = R.col_tab && !R.use_rng && R.first_batch && R.sample_begin == 0u && R.sample_end == 1u;
+    const bool plain = R.window_width == 0.0 && !R.use_rng && R.first_batch && R.sample_begin == 0u && R.sample_end == 1u && R.width <= 16384u && R.height <= 16384u;
     const bool mesh_only = features == 2 || features == 6 || features == 18 || features == 22;
     if (occ == 3) { // the three-wave builds of the alpha-shadow mesh permutations: + kFeatNoXform when every BLAS is untransformed, + kFeatPark
         if (features == 6 || features == 22) { if (launch(false, features + (noxform ? (int)kFeatNoXform : 0) + (park ? (int)kFeatPark : 0), plain, 3)) return; }
@@ -444,6 +478,22 @@ static void launch_primary(bool instrumented, int features, bool noxform, bool p
     if (plain && launch(false, features, true, 0)) return;
     if (launch(false, features, false, 0)) return;
     launch(false, kFeatAll, false, 0); // bit 8 (double branching) only in the full kernels
+}
+
+// The ring's timing events are created by the first frame that records into a slot (1 024 hipEventCreate cost 0.6 ms of every scene creation; the
+// first slots are created with the handle).  Every handle of the slot is checked: a creation that failed half-way is retried by the next frame.
+static int ensure_ring_slot(NraysScene* sc, int slot) {
+    hipEvent_t* ev[4] = {&sc->ev_begin[slot], &sc->ev_pbegin[slot], &sc->ev_pend[slot], &sc->ev_end[slot]};
+    for (hipEvent_t* e : ev) if (!*e && hipEventCreate(e) != hipSuccess) { *e = nullptr; return fail(NRAYS_ERR_HIP, "event creation failed"); }
+    return NRAYS_OK;
+}
+
+// analytic scenes: the sums / maxima k_tile_order reports per list, their pinned landing place and the event behind the read-back
+static int alloc_cost_stats(NraysScene* sc) {
+    HIP_TRY(hipMalloc((void**)&sc->d_cost_stats, 16 * sizeof(unsigned long long)));
+    HIP_TRY(hipHostMalloc((void**)&sc->h_cost_stats, 16 * sizeof(unsigned long long), hipHostMallocDefault));
+    HIP_TRY(hipEventCreateWithFlags(&sc->ev_stats, hipEventDisableTiming));
+    return NRAYS_OK;
 }
 
 static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out, hipStream_t stream, bool instrumented) {
@@ -489,7 +539,7 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
     R.width = p->width; R.height = p->height; R.rows_local = rows; R.spp = p->ray_per_pixel;
     R.max_depth = p->max_depth;
     R.band_rows = p->band_rows; R.band_owner = p->band_owner; R.band_owners = p->band_owners ? p->band_owners : 1;
-    R.window_width = p->window_width;
+    R.window_width = p->window_width; R.inv_width = 1.0 / (double)p->width; R.inv_height = 1.0 / (double)p->height;
     for (int a = 0; a < 3; ++a) R.eye[a] = p->camera_eye[a];
     for (int a = 0; a < 16; ++a) R.m[a] = p->inv_proj_view[a];
     R.seed = p->seed;
@@ -563,10 +613,7 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
     const bool timed = instrumented || (sc->frames_total % sc->event_stride) == 0;
     sc->frames_total++;
     const int slot = (int)(sc->frames_recorded % NraysScene::kRing);
-    if (timed && !sc->ev_begin[slot])
-        if (hipEventCreate(&sc->ev_begin[slot]) != hipSuccess || hipEventCreate(&sc->ev_pbegin[slot]) != hipSuccess ||
-            hipEventCreate(&sc->ev_pend[slot]) != hipSuccess || hipEventCreate(&sc->ev_end[slot]) != hipSuccess)
-            return fail(NRAYS_ERR_HIP, "event creation failed");
+    if (timed) { const int rc_ = ensure_ring_slot(sc, slot); if (rc_ != NRAYS_OK) return rc_; }
     // events: [pbegin .. pend] brackets the first primary launch; the frame spans [pbegin .. end], and
     // `end` is only recorded separately when something follows the primary kernel
     // The staged ("wavefront") form of the trace loop (wavefront.hip) renders this frame instead of k_primary when the scene is eligible and
@@ -577,22 +624,6 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
     DeviceCounters* next_ctr = sc->d_counters_set[(sc->frame_index + 1) & 1];
     sc->frame_index++;
     R.use_rng = (p->window_width != 0.0 || sc->host.any_area_light) ? 1u : 0u;
-    R.col_tab = nullptr; R.row_tab = nullptr;
-    if (p->window_width == 0.0) { // jitter-free camera: (re)build the raygen tables only when the camera or the resolution changed
-        size_t need = 4 * ((size_t)p->width + p->height);
-        if (need > sc->tables_doubles) {
-            if (sc->d_tables) { (void)hipFree(sc->d_tables); sc->d_tables = nullptr; sc->tables_doubles = 0; }
-            HIP_TRY(hipMalloc((void**)&sc->d_tables, need * sizeof(double)));
-            sc->tables_doubles = need; sc->tab_valid = false;
-        }
-        R.col_tab = sc->d_tables; R.row_tab = sc->d_tables + 4 * (size_t)p->width;
-        if (!sc->tab_valid || sc->tab_w != p->width || sc->tab_h != p->height || std::memcmp(sc->tab_m, p->inv_proj_view, sizeof sc->tab_m) != 0) {
-            uint32_t n = p->width + p->height;
-            hipLaunchKernelGGL(k_raygen_tables, dim3((n + 255) / 256), dim3(256), 0, stream, sc->d_tables, sc->d_tables + 4 * (size_t)p->width, p->width, p->height, R);
-            HIP_TRY(hipGetLastError());
-            sc->tab_w = p->width; sc->tab_h = p->height; std::memcpy(sc->tab_m, p->inv_proj_view, sizeof sc->tab_m); sc->tab_valid = true;
-        }
-    }
     // mesh scenes: longest-processing-time-first from the previous frame of the same geometry (pixels do not depend on it)
     R.tile_cost = nullptr; R.tile_order = nullptr;
     sc->has_prepass[slot] = false;
@@ -606,6 +637,24 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
         const int rc = wavefront_render(sc, p, R, d_out, stream, tiles_x, tiles_y, timed, slot, next_ctr, next_counts);
         if (rc != NRAYS_OK) return rc;
     } else {
+    // ---- per-camera scheduling state (pixels never depend on it) -----------------------------------------------------------------
+    // The reference's caller renders every camera ONCE (examples/loader3d.rs:67-93), an interactive caller moves it a little every
+    // frame: what a frame may cost besides its tiles is decided here.
+    //   resting camera    the order recorded for it is reused; nothing is recorded, nothing sorted;
+    //   nearby camera     (shift of the view since the order's camera below kNearPixels, cam_shift_px()) the order is reused as it is for
+    //                     up to kMaxOrderAge frames; the last of them records its tile costs, the next one sorts them (ONE k_tile_order,
+    //                     which also clears the cost array) — a moving camera pays the sort every kMaxOrderAge + 1 frames;
+    //   cold camera       no usable history: mesh scenes guess (k_seed_costs + k_tile_order), analytic scenes run image-order lists;
+    //                     the frame records its costs, its successor sorts them.
+    const uint64_t sched_key = (((uint64_t)p->width << 40) ^ ((uint64_t)rows << 20) ^ ((uint64_t)p->band_rows << 8) ^ ((uint64_t)p->band_owner << 4) ^ (uint64_t)R.band_owners ^ ((uint64_t)lane_log2 << 60))
+                               + 0x9E3779B97F4A7C15ull * (((uint64_t)R.win_x0 << 48) ^ ((uint64_t)R.win_nx << 32) ^ ((uint64_t)R.win_y0 << 16) ^ (uint64_t)R.win_ny);
+    uint64_t cam = 0xcbf29ce484222325ull; // FNV-1a over everything a tile's cost depends on besides the scene (which a handle never changes)
+    { auto mix = [&](const void* q, size_t n) { const unsigned char* b_ = (const unsigned char*)q; for (size_t i = 0; i < n; ++i) { cam ^= b_[i]; cam *= 0x100000001b3ull; } };
+      mix(p->inv_proj_view, sizeof p->inv_proj_view); mix(p->camera_eye, sizeof p->camera_eye); mix(&p->window_width, sizeof p->window_width);
+      mix(&p->ray_per_pixel, sizeof p->ray_per_pixel); mix(&p->max_depth, sizeof p->max_depth); }
+    const CamSnap snap = cam_snapshot(sc->host, p);
+    auto near_cam = [&](const CamSnap& other) { return sc->near_reuse && cam_shift_px(other, snap) <= sc->near_pixels; };
+    const uint32_t kMaxOrderAge = sc->max_order_age;
     bool lpt = grab >= 1u && lane_log2 == 0u;
     lpt = lpt && sc->lpt_enabled; // A/B switch (NRAYS_LPT=0)
     if (instrumented && sc->light_lsl) lpt = false; // the instrumented kernel does not decode the split entries a plain frame's order may hold
@@ -626,39 +675,46 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
         }
         if (split_lsl && !sc->d_order_len) HIP_TRY(hipMalloc((void**)&sc->d_order_len, 8 * sizeof(uint32_t)));
         R.light_lsl = split_lsl; R.order_len = split_lsl ? sc->d_order_len : nullptr;
-        const uint64_t key = (((uint64_t)p->width << 40) ^ ((uint64_t)rows << 20) ^ ((uint64_t)p->band_rows << 8) ^ ((uint64_t)p->band_owner << 4) ^ (uint64_t)R.band_owners ^ ((uint64_t)lane_log2 << 60))
-                             + 0x9E3779B97F4A7C15ull * (((uint64_t)R.win_x0 << 48) ^ ((uint64_t)R.win_nx << 32) ^ ((uint64_t)R.win_y0 << 16) ^ (uint64_t)R.win_ny);
-        // everything a tile's cost depends on besides the scene (which a handle never changes): a resting camera reuses its order
-        // and records nothing — k_tile_order and the two s_memtime + one store per tile are only paid while the camera moves
-        uint64_t cam = 0xcbf29ce484222325ull; // FNV-1a
-        auto mix = [&](const void* q, size_t n) { const unsigned char* b = (const unsigned char*)q; for (size_t i = 0; i < n; ++i) { cam ^= b[i]; cam *= 0x100000001b3ull; } };
-        mix(p->inv_proj_view, sizeof p->inv_proj_view); mix(p->camera_eye, sizeof p->camera_eye); mix(&p->window_width, sizeof p->window_width);
-        mix(&p->ray_per_pixel, sizeof p->ray_per_pixel); mix(&p->max_depth, sizeof p->max_depth);
-        if (sc->order_valid && sc->order_key == key && sc->order_cam == cam && sc->lpt_reuse) {
-            R.tile_order = sc->d_tile_order;
-            grab = 1u;
+        const uint64_t key = sched_key ^ ((uint64_t)split_lsl << 56); // (an order that holds split entries is not one without them)
+        const bool order_here = sc->order_valid && sc->order_key == key && !sc->order_seeded && sc->lpt_reuse;
+        bool record = false;
+        if (order_here && sc->order_cam == cam) {
+            R.tile_order = sc->d_tile_order; // resting camera
+        } else if (order_here && kMaxOrderAge != 0u && sc->order_age < kMaxOrderAge && near_cam(sc->order_snap)) {
+            R.tile_order = sc->d_tile_order; // nearby camera: the order as it is
+            record = ++sc->order_age == kMaxOrderAge;
+            if (record && split_lsl) HIP_TRY(hipMemsetAsync(sc->d_tile_cost, 0, (size_t)nwt * sizeof(uint32_t), stream)); // split entries record by atomicMax (rare frame: every kMaxOrderAge-th)
         } else {
-            // no history for this geometry: a first guess from the boxes of the nodes that can continue a chain (k_seed_costs)
-            const bool seeded = !(sc->cost_valid && sc->cost_key == key) && sc->seed_enabled && sc->seed_boxes != 0u && lane_log2 == 0u && win_units > 0;
+            const bool costs_here = sc->cost_valid && sc->cost_key == key && (sc->cost_cam == cam || near_cam(sc->cost_snap));
+            // no history for this view: a first guess from the boxes of the nodes that can continue a chain (k_seed_costs)
+            const bool seeded = !costs_here && sc->seed_enabled && sc->seed_boxes != 0u && win_units > 0;
             if (seeded) {
                 if (timed) HIP_TRY(hipEventRecord(sc->ev_begin[slot], stream));
                 hipLaunchKernelGGL(k_seed_costs, dim3((nwt + 255u) / 256u), dim3(256), 0, stream, R, (const float*)sc->d_seed_boxes, sc->seed_boxes, sc->d_tile_cost, nwt, sc->seed_rays);
                 HIP_TRY(hipGetLastError());
+#ifdef NR_DEBUG_TILE_COSTS
+                if (!sc->d_seed_copy) HIP_TRY(hipMalloc((void**)&sc->d_seed_copy, (size_t)sc->tile_slots * sizeof(uint32_t)));
+                HIP_TRY(hipMemcpyAsync(sc->d_seed_copy, sc->d_tile_cost, (size_t)nwt * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream)); // tools/tile_dump.py: the guess beside the recorded costs
+#endif
             }
-            if (seeded || (sc->cost_valid && sc->cost_key == key)) {
+            if (seeded || costs_here) {
                 if (timed && !seeded) HIP_TRY(hipEventRecord(sc->ev_begin[slot], stream));
                 sc->has_prepass[slot] = true;
                 hipLaunchKernelGGL(k_tile_order, dim3(8), dim3(1024), 0, stream, sc->d_tile_cost, sc->d_tile_order, nwt, (unsigned long long*)nullptr,
-                                   split_lsl, sc->light_split_factor, grid_primary * (uint32_t)(kBlock / 64), split_lsl ? sc->d_order_len : (uint32_t*)nullptr);
+                                   split_lsl, sc->light_split_factor, grid_primary * (uint32_t)(kBlock / 64), split_lsl ? sc->d_order_len : (uint32_t*)nullptr, split_lsl ? 1u : 0u, sc->split_hyst);
                 HIP_TRY(hipGetLastError());
                 R.tile_order = sc->d_tile_order;
-                grab = 1u;
-                sc->order_valid = true; sc->order_key = key; sc->order_cam = seeded ? ~cam : sc->cost_cam; // (a guessed order is replaced by the recorded one on the next frame)
-            }
-            R.tile_cost = sc->d_tile_cost;
-            if (split_lsl && R.tile_order) HIP_TRY(hipMemsetAsync(sc->d_tile_cost, 0, (size_t)nwt * sizeof(uint32_t), stream)); // (after k_tile_order read it: split entries record by atomicMax)
-            sc->cost_key = key; sc->cost_cam = cam; sc->cost_valid = true;
+                sc->order_valid = true; sc->order_key = key; sc->order_seeded = seeded; sc->order_age = 0;
+                if (!seeded) { sc->order_cam = sc->cost_cam; sc->order_snap = sc->cost_snap; }
+            } else if (split_lsl) HIP_TRY(hipMemsetAsync(sc->d_tile_cost, 0, (size_t)nwt * sizeof(uint32_t), stream));
+            // a guessed order is replaced by the recorded one on the next frame; an order sorted from a NEARBY camera's costs serves this
+            // one as it is (it ages like any other).  The frame that sorts its OWN camera's costs records once more: under the order it will
+            // keep (nrays_get_tile_costs reports these).
+            record = seeded || !costs_here || !sc->lpt_reuse || sc->cost_cam == cam || kMaxOrderAge == 0u;
+            if (!record) sc->cost_valid = false; // consumed (and, with split entries, cleared) by the sort
         }
+        if (R.tile_order) grab = 1u;
+        if (record) { R.tile_cost = sc->d_tile_cost; sc->cost_key = key; sc->cost_cam = cam; sc->cost_snap = snap; sc->cost_valid = true; }
     }
     // Analytic scenes (workgroup lists): the frames are a few hundred long tiles (deep reflection chains, ~10^5 cycles each) among
     // thousands of short ones, and a long tile runs ~1.5x faster when it does not share its SIMD with another long one.  The first
@@ -676,47 +732,44 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
             HIP_TRY(hipMalloc((void**)&sc->d_tile_order, (size_t)nwt * sizeof(uint32_t)));
             sc->tile_slots = nwt;
         }
-        if (!sc->d_cost_stats) {
-            HIP_TRY(hipMalloc((void**)&sc->d_cost_stats, 2 * sizeof(unsigned long long)));
-            HIP_TRY(hipHostMalloc((void**)&sc->h_cost_stats, 2 * sizeof(unsigned long long), hipHostMallocDefault));
-            HIP_TRY(hipEventCreateWithFlags(&sc->ev_stats, hipEventDisableTiming));
-        }
-        const uint64_t key = (((uint64_t)p->width << 40) ^ ((uint64_t)rows << 20) ^ ((uint64_t)p->band_rows << 8) ^ ((uint64_t)p->band_owner << 4) ^ (uint64_t)R.band_owners ^ ((uint64_t)lane_log2 << 60))
-                             + 0x9E3779B97F4A7C15ull * (((uint64_t)R.win_x0 << 48) ^ ((uint64_t)R.win_nx << 32) ^ ((uint64_t)R.win_y0 << 16) ^ (uint64_t)R.win_ny);
-        uint64_t cam = 0xcbf29ce484222325ull; // FNV-1a over everything a tile's cost depends on
-        auto mix = [&](const void* q, size_t n) { const unsigned char* b = (const unsigned char*)q; for (size_t i = 0; i < n; ++i) { cam ^= b[i]; cam *= 0x100000001b3ull; } };
-        mix(p->inv_proj_view, sizeof p->inv_proj_view); mix(p->camera_eye, sizeof p->camera_eye); mix(&p->window_width, sizeof p->window_width);
-        mix(&p->ray_per_pixel, sizeof p->ray_per_pixel); mix(&p->max_depth, sizeof p->max_depth);
+        if (!sc->d_cost_stats) { int rc_ = alloc_cost_stats(sc); if (rc_ != NRAYS_OK) return rc_; }
+        const uint64_t key = sched_key;
         const hipError_t stats_ready = sc->stats_pending ? hipEventQuery(sc->ev_stats) : hipErrorNotReady;
         if (sc->stats_pending && stats_ready != hipSuccess) (void)hipGetLastError(); // "not ready" must not surface as the launch error checked below
-        if (sc->stats_pending && stats_ready == hipSuccess) { // the sum / maximum of the last sort have arrived
-            const double sum = (double)sc->h_cost_stats[0], mx = (double)sc->h_cost_stats[1];
+        if (sc->stats_pending && stats_ready == hipSuccess) { // the sums / maxima of the last sort's eight lists have arrived
+            double sum = 0.0, mx = 0.0;
+            for (int x = 0; x < 8; ++x) { sum += (double)sc->h_cost_stats[2 * x]; mx = std::max(mx, (double)sc->h_cost_stats[2 * x + 1]); }
             sc->lone_waves = mx > 0.0 && sum / mx < sc->lone_factor * 4.0 * (double)sc->num_cus;
+            sc->lone_known = true; sc->lone_key = sc->stats_key;
             sc->stats_pending = false;
         }
         auto sort_costs = [&]() -> int {
             if (sc->stats_pending) HIP_TRY(hipEventSynchronize(sc->ev_stats)); // (a camera that changes every few frames: the previous read-back is long done)
             if (timed) HIP_TRY(hipEventRecord(sc->ev_begin[slot], stream));
             sc->has_prepass[slot] = true;
-            HIP_TRY(hipMemsetAsync(sc->d_cost_stats, 0, 2 * sizeof(unsigned long long), stream));
-            hipLaunchKernelGGL(k_tile_order, dim3(8), dim3(1024), 0, stream, sc->d_tile_cost, sc->d_tile_order, nwt, sc->d_cost_stats, 0u, 0.0f, 0u, (uint32_t*)nullptr);
+            hipLaunchKernelGGL(k_tile_order, dim3(8), dim3(1024), 0, stream, sc->d_tile_cost, sc->d_tile_order, nwt, sc->d_cost_stats, 0u, 0.0f, 0u, (uint32_t*)nullptr, 0u, 1.0f);
             HIP_TRY(hipGetLastError());
-            HIP_TRY(hipMemcpyAsync(sc->h_cost_stats, sc->d_cost_stats, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipMemcpyAsync(sc->h_cost_stats, sc->d_cost_stats, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipEventRecord(sc->ev_stats, stream));
-            sc->stats_pending = true;
-            sc->order_valid = true; sc->order_key = key; sc->order_cam = sc->cost_cam; sc->order_age = 0;
+            sc->stats_pending = true; sc->stats_key = key;
+            sc->order_valid = true; sc->order_key = key; sc->order_cam = sc->cost_cam; sc->order_snap = sc->cost_snap; sc->order_age = 0;
             return NRAYS_OK;
         };
-        if (sc->order_valid && sc->order_key == key && sc->order_cam == cam) {
+        const bool order_here = sc->order_valid && sc->order_key == key;
+        bool record = false;
+        if (order_here && sc->order_cam == cam) {
             // steady state of a resting camera: nothing recorded, nothing sorted
-        } else if (sc->cost_valid && sc->cost_key == key && sc->cost_cam == cam) {
-            const int rc = sort_costs(); if (rc != NRAYS_OK) return rc; // second frame of this camera
-        } else { // a new camera: record its costs; the order of a nearby camera of the same geometry is still a good guess
-            if (sc->cost_valid && sc->cost_key == key && (!sc->order_valid || sc->order_key != key || sc->order_age >= 8u)) { const int rc = sort_costs(); if (rc != NRAYS_OK) return rc; }
-            if (sc->order_valid && sc->order_key == key) sc->order_age++;
-            R.tile_cost = sc->d_tile_cost; sc->cost_key = key; sc->cost_cam = cam; sc->cost_valid = true;
+        } else if (order_here && sc->order_age < kMaxOrderAge && near_cam(sc->order_snap)) {
+            record = ++sc->order_age == kMaxOrderAge; // nearby camera: the order as it is; its last frame records for the re-sort
+        } else if (sc->cost_valid && sc->cost_key == key && (sc->cost_cam == cam || near_cam(sc->cost_snap))) {
+            const int rc = sort_costs(); if (rc != NRAYS_OK) return rc; // the frame after a recording one
+        } else {
+            sc->order_valid = false; // a cold camera: image-order lists, costs recorded
+            record = true;
         }
-        if (sc->order_valid && sc->order_key == key && sc->lone_waves && !sc->stats_pending) {
+        if (record) { R.tile_cost = sc->d_tile_cost; sc->cost_key = key; sc->cost_cam = cam; sc->cost_snap = snap; sc->cost_valid = true; }
+        // (while the sums of a re-sort are on their way the decision of the previous sort of this geometry stands)
+        if (sc->order_valid && sc->order_key == key && sc->lone_known && sc->lone_key == key && sc->lone_waves) {
             R.tile_order = sc->d_tile_order;
             if (sc->lead_mode) { R.lead_wgs = std::min<uint32_t>(grid_primary, (uint32_t)sc->num_cus); R.lead_entries = R.lead_wgs * (uint32_t)sc->lead_per_wg; } // two workgroups per CU: one of them owns the long tiles
             else grid_primary = std::min<uint32_t>(grid_primary, (uint32_t)sc->num_cus);             // NRAYS_LEAD_WGS=0: one workgroup per CU
@@ -876,6 +929,23 @@ int nrays_scene_create(const NraysSceneDesc* desc, NraysScene** out_scene) {
             if (hipMemcpy(blk, stage.data(), total, hipMemcpyHostToDevice) != hipSuccess) return bail(fail(NRAYS_ERR_HIP, "record upload failed"));
         }
     }
+    {   // the elisions (trace_device.h: light_is_dark, shade_hit) need x * 0 == 0 for everything they skip: any non-finite light, material colour or float texel, or a
+        // negative shininess (0 * inf), switches them off for this scene (phong_material.rs:109-141, scene.rs:179-190 then produce NaN, and so do we)
+        bool finite = true;
+        for (const LightRec& l : h.lights) { for (int a = 0; a < 3; ++a) finite = finite && std::isfinite(l.pos[a]) && std::isfinite(l.color[a]); finite = finite && std::isfinite(l.radius); }
+        for (const ShadeRec& m : h.shade) {
+            for (int a = 0; a < 3; ++a) finite = finite && std::isfinite(m.ka[a]) && std::isfinite(m.kd[a]) && std::isfinite(m.ks[a]);
+            finite = finite && std::isfinite(m.shininess) && m.shininess >= 0.0f && std::isfinite(m.alpha) && std::isfinite(m.refl_mix) && std::isfinite(m.refl_atenuation) && std::isfinite(m.refr_coeff);
+        }
+        for (const HostTexture& t : h.textures) {
+            if (t.rec.format != NRAYS_TEXEL_RGBA32F) continue;
+            const float* f = (const float*)t.bytes.data();
+            for (size_t i = 0, n = t.bytes.size() / sizeof(float); i < n && finite; ++i) finite = std::isfinite(f[i]);
+        }
+        for (int a = 0; a < 3; ++a) finite = finite && std::isfinite(h.background[a]);
+        const char* e = getenv("NRAYS_ELIDE"); // =0: never (A/B)
+        sc->d.no_elide = (!finite || (e && atoi(e) == 0)) ? 1u : 0u;
+    }
     std::vector<TextureRec> trecs;
     for (HostTexture& t : h.textures) {
         void* p = nullptr;
@@ -986,6 +1056,15 @@ int nrays_scene_create(const NraysSceneDesc* desc, NraysScene** out_scene) {
     if (const char* e = getenv("NRAYS_WAVEFRONT")) sc->wavefront_mode = atoi(e);
     if (const char* e = getenv("NRAYS_LPT_ANALYTIC")) sc->lpt_analytic = atoi(e) != 0;
     if (const char* e = getenv("NRAYS_LPT_REUSE")) sc->lpt_reuse = atoi(e) != 0;
+    if (const char* e = getenv("NRAYS_NEAR_REUSE")) sc->near_reuse = atoi(e) != 0;
+    // Mesh scenes re-sort on every frame of a moving camera (age 0): the deep foliage chains of the sponza stand-in move between tiles with every pixel of camera motion, and a
+    // frame that reuses an order a few frames old waits for tiles it started late — 1.20 ms against 1.145 with the previous frame's costs, 1.04 at rest
+    // (profiles/r06_regimes_sweep.log).  Analytic scenes keep an order for 16 frames of a camera within two blocks (balls, moving: 0.0576 ms at 8 frames / 16 pixels,
+    // 0.0565 at 16 / 64, 0.0550 with an order that is never refreshed; 0.049 at rest).
+    sc->near_pixels = sc->host.any_mesh ? kNearPixels : 2.0 * kNearPixels; sc->max_order_age = sc->host.any_mesh ? 0u : 16u;
+    if (const char* e = getenv("NRAYS_SPLIT_HYST")) sc->split_hyst = (float)atof(e);
+    if (const char* e = getenv("NRAYS_NEAR_PIXELS")) sc->near_pixels = atof(e);
+    if (const char* e = getenv("NRAYS_ORDER_AGE")) sc->max_order_age = (uint32_t)std::max(0, atoi(e));
     if (const char* e = getenv("NRAYS_LEAD_WGS")) sc->lead_mode = atoi(e) != 0;
     if (const char* e = getenv("NRAYS_LONE_FACTOR")) sc->lone_factor = atof(e);
     if (const char* e = getenv("NRAYS_LEAD_PER_WG")) sc->lead_per_wg = std::max(1, std::min(64, atoi(e)));
@@ -1012,13 +1091,15 @@ int nrays_scene_create(const NraysSceneDesc* desc, NraysScene** out_scene) {
         // renders a camera ONCE (loader3d.rs:67-93), so the first frame of a handle is the one that counts for it.
         const char* e = getenv("NRAYS_PREALLOC"); // =0: allocate on the first frame (A/B switch)
         if (!(e && atoi(e) == 0)) {
-            const size_t tab = 4 * (size_t)(3840 + 2160);
-            if (hipMalloc((void**)&sc->d_tables, tab * sizeof(double)) == hipSuccess) sc->tables_doubles = tab; else { sc->d_tables = nullptr; (void)hipGetLastError(); }
             const uint32_t nwt = (3840u / 16u) * (2160u / 16u) * 4u;
             if (hipMalloc((void**)&sc->d_tile_cost, (size_t)nwt * sizeof(uint32_t)) == hipSuccess &&
                 hipMalloc((void**)&sc->d_tile_order, order_slots(nwt, sc->light_lsl) * sizeof(uint32_t)) == hipSuccess) sc->tile_slots = nwt;
             else { if (sc->d_tile_cost) (void)hipFree(sc->d_tile_cost); sc->d_tile_cost = nullptr; sc->d_tile_order = nullptr; (void)hipGetLastError(); }
             if (sc->light_lsl && hipMalloc((void**)&sc->d_order_len, 8 * sizeof(uint32_t)) != hipSuccess) { sc->d_order_len = nullptr; (void)hipGetLastError(); }
+            // ... the analytic scenes' read-back buffers, the event a render on another stream waits for, and the ring's first slots
+            if (!sc->host.any_mesh && alloc_cost_stats(sc) != NRAYS_OK) { (void)hipGetLastError(); }
+            if (hipEventCreateWithFlags(&sc->ev_switch, hipEventDisableTiming) != hipSuccess) { sc->ev_switch = nullptr; (void)hipGetLastError(); }
+            for (int k = 0; k < 8; ++k) (void)ensure_ring_slot(sc, k);
             if (sc->spill_entries && hipMalloc((void**)&sc->d_spill, (size_t)kMaxGrid * kBlock * sc->spill_entries * sizeof(uint32_t)) != hipSuccess) { sc->d_spill = nullptr; (void)hipGetLastError(); }
         }
     }
@@ -1041,7 +1122,6 @@ void nrays_scene_destroy(NraysScene* sc) {
     if (sc->d_spill) (void)hipFree(sc->d_spill);
     if (sc->d_fixed) (void)hipFree(sc->d_fixed);
     if (sc->d_frame) (void)hipFree(sc->d_frame);
-    if (sc->d_tables) (void)hipFree(sc->d_tables);
     if (sc->d_tile_cost) (void)hipFree(sc->d_tile_cost);
     if (sc->d_tile_order) (void)hipFree(sc->d_tile_order);
     if (sc->d_order_len) (void)hipFree(sc->d_order_len);
@@ -1114,18 +1194,15 @@ int nrays_get_tile_costs(NraysScene* sc, NraysTileCosts* out) {
     HIP_TRY(hipStreamSynchronize(sc->last_stream));
     std::vector<uint32_t> c(sc->cost_tiles);
     HIP_TRY(hipMemcpy(c.data(), sc->d_tile_cost, c.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    // The unit the schedule deals is a wave tile — or ONE PART of a tile the cost-ordered lists split (k_tile_order: tiles at or above light_split_factor x the frame's work per
-    // resident wave; a part's cycles were recorded x 2^lsl, or x 3 for the pixel-split tiles of one-light frames).  max_cycles is the longest such unit, sum_cycles what the
-    // waves spend: every part of a split tile counted.
+    // The unit the schedule deals is a wave tile — or ONE PART of a tile the cost-ordered lists split: k_primary marks the record of a tile that ran in parts
+    // (kCostSplit; the value is its most expensive part's cycles x 2^lsl, or x 3 for the pixel-split tiles of one-light frames).  max_cycles is the longest such
+    // unit, sum_cycles what the waves spend: every part of a split tile counted (at its most expensive part's price: an upper bound).
     const uint32_t lsl = sc->cost_split_lsl;
     const bool multi = (sc->features & kFeatMultiSample) != 0;
-    uint64_t rec_sum = 0;
-    for (uint32_t v : c) rec_sum += v;
-    const uint64_t waves = std::max<uint64_t>(1, (uint64_t)sc->cost_grid * (kBlock / 64));
-    const double thr = !lsl || sc->light_split_factor == 0.0f ? 1e300 : (sc->light_split_factor < 0.0f ? 0.0 : (double)sc->light_split_factor * (double)rec_sum / (double)waves);
-    for (uint32_t v : c) {
+    for (uint32_t rec : c) {
+        const uint32_t v = rec & kCostMask;
         uint64_t unit = v, n = 1;
-        if (lsl && v != 0u && (double)v >= thr) { unit = multi ? (uint64_t)(v >> lsl) : (uint64_t)(v / 3u); n = 1ull << lsl; }
+        if (lsl && (rec & kCostSplit)) { unit = multi ? (uint64_t)(v >> lsl) : (uint64_t)(v / 3u); n = 1ull << lsl; }
         out->sum_cycles += unit * n * 16u; out->max_cycles = std::max<uint64_t>(out->max_cycles, unit * 16u);
     }
     out->tiles = c.size(); out->resident_waves = (uint64_t)sc->cost_grid * (kBlock / 64);
@@ -1144,6 +1221,15 @@ int nrays_debug_tile_costs(NraysScene* sc, uint32_t* out, uint32_t capacity, uin
 }
 #endif
 #ifdef NR_DEBUG_TILE_COSTS
+// Tuning builds only (tools/tile_dump.py): k_seed_costs' guess of the last cold frame.
+int nrays_debug_seed_costs(NraysScene* sc, uint32_t* out, uint32_t capacity, uint32_t* out_count) {
+    if (!sc || !sc->have_last || !sc->d_seed_copy) return NRAYS_ERR_BAD_ARG;
+    HIP_TRY(hipStreamSynchronize(sc->last_stream));
+    const uint32_t n = std::min(capacity, sc->tile_slots);
+    HIP_TRY(hipMemcpy(out, sc->d_seed_copy, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    *out_count = n;
+    return NRAYS_OK;
+}
 // Tuning builds only (tools/wave_timeline.py): {kernel entry, first tile, exit, tiles} per wave of the last primary launch, 10 ns ticks.
 int nrays_debug_wave_times(NraysScene* sc, uint32_t* out, uint32_t capacity_waves, uint32_t* out_waves) {
     if (!sc || !sc->have_last || !sc->d_wave_times) return NRAYS_ERR_BAD_ARG;

@@ -4,6 +4,7 @@
 // kernels compile side by side; nrays_hip.hip holds the host side and the small kernels.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstddef>
 #ifndef NR_TILE_PRIO
 #define NR_TILE_PRIO 0 // k < NR_TILE_PRIO: priority 3, < 3x: 2, < 8x: 1 (0 = off)
 #endif
@@ -93,7 +94,7 @@ __device__ __forceinline__ void flush_counters(DeviceCounters* ctr, const Cnt& c
 #endif
     if (__lane_id() == 0) {
         if (sh) atomicAdd(&ctr->rays_shadow, (unsigned long long)sh);
-        if (el) atomicAdd(&ctr->shadow_elided, el);
+        if (el) atomicAdd(&ctr->shadow_elided, (unsigned long long)el);
         if (rl) atomicAdd(&ctr->rays_reflection, (unsigned long long)rl);
         if (rf) atomicAdd(&ctr->rays_refraction, (unsigned long long)rf);
         if (md) atomicMax(&ctr->max_depth, md);
@@ -180,6 +181,9 @@ __global__ void __launch_bounds__(kBlock, OCC ? NR_OCC3_AS : waves_per_simd(FEAT
     unsigned long long twave = __builtin_readcyclecounter();
 #endif
 
+    // DRender::m as it lies in the kernel-argument segment (R is the second argument, behind S0; both 8-byte aligned): generate_primary<PLAIN> reads it with vector loads
+    static_assert(alignof(DScene) == 8 && alignof(DRender) == 8 && sizeof(DScene) % 8 == 0, "kernel-argument layout of k_primary");
+    const double* m_mem = (const double*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + sizeof(DScene) + offsetof(DRender, m));
     const uint32_t lane = threadIdx.x & 63u;
     // (one-light scenes with transparent nodes too — NR_PIXEL_SPLIT: a part is then 64 >> lsl PIXELS of the tile, every pixel's 2^lsl lanes tracing the same rays; what it
     // buys is that the deep, divergent chains through alpha-mapped layers of 8 pixels serialise in a wave instead of those of 64)
@@ -373,7 +377,7 @@ __global__ void __launch_bounds__(kBlock, OCC ? NR_OCC3_AS : waves_per_simd(FEAT
             if (!tile_misses) {
                 // lanes outside the frame (ragged right edge, padding rows of a band) still execute the ray generation: keep
                 // their table reads inside the tables
-                generate_primary<PLAIN>(R, i < R.width ? i : R.width - 1u, j < R.height ? j : R.height - 1u, s, pix, ray);
+                generate_primary<PLAIN>(R, i < R.width ? i : R.width - 1u, j < R.height ? j : R.height - 1u, s, pix, ray, PLAIN ? m_mem : nullptr);
                 wave_may_hit = __ballot(sample_active && primary_may_hit(S, ray.o, ray.d)) != 0ULL;
             }
             NR_TOC(cyc_x[1], trg);
@@ -424,11 +428,13 @@ __global__ void __launch_bounds__(kBlock, OCC ? NR_OCC3_AS : waves_per_simd(FEAT
             // 2 - 3 parts' time — so that a tile a first guess split without need, e.g. in a 4K frame, is whole again once its cost is known)
             unsigned long long dt = (__builtin_readcyclecounter() - tile_t0) >> 4;
             if (kLightSplit && lsl) dt = (FEAT & kFeatMultiSample) ? dt << lsl : dt * 3u;
-            const uint32_t c = dt > 0xffffffffULL ? 0xffffffffu : (uint32_t)dt;
+            const uint32_t c = dt > (unsigned long long)kCostMask ? kCostMask : (uint32_t)dt;
             // a light-parallel tile: its most expensive part stands for all (the array is cleared before a frame that records into split entries) — the
             // first part alone is eight of the tile's pixels, and a tile priced by a cheap row stayed whole and late in the order: one rank of eight
             // of config 4 ran 1.82 ms for 1.25 (profiles/r05_rank_occupancy.log)
-            if (kLightSplit && lsl) atomicMax(&R.tile_cost[wt], c); else R.tile_cost[wt] = c;
+            // (kCostSplit marks the record of a tile that ran in parts: the next sort keeps it split down to half the threshold — a part x 3 can underestimate the whole tile, and a
+            // tile that is split one frame and whole the next makes every second frame of a moving camera wait for an unsplit monster — and nrays_get_tile_costs knows the units dealt)
+            if (kLightSplit && lsl) atomicMax(&R.tile_cost[wt], c | kCostSplit); else R.tile_cost[wt] = c;
         }
       }
       if (grab == 1u) pending = issue_grab(work_counters, victim, grab);

@@ -20,6 +20,10 @@ struct QueueMem {
     void* block = nullptr;
 };
 
+// A camera as the scheduler sees it (nrays_hip.hip: cam_snapshot): eye, unit rays through the four corners of the frame, the angle of a pixel,
+// the distance to the scene's bounding box.
+struct CamSnap { double eye[3] = {0, 0, 0}; double dir[4][3] = {}; double pix_angle = 0.0, depth = 1.0; bool valid = false; };
+
 constexpr int kNumCounts = kMaxGenerations + 2 + 8; // queue round counters + 8 per-XCD work counters
 constexpr int kMaxGrid = 2048;     // upper bound of the persistent grid (the launch uses CUs x waves/SIMD workgroups)
 
@@ -44,8 +48,6 @@ struct NraysScene {
     uint32_t* d_spill = nullptr;
     long long* d_fixed = nullptr; size_t fixed_slots = 0; // per-pixel fixed-point sums of the queued chains (double-branching scenes)
     bool fixed_dirty = false; // k_bounce rounds were enqueued and their k_fold_fixed was not (an error in between): cleared at the next frame's start
-    double* d_tables = nullptr; size_t tables_doubles = 0; // raygen tables: 4 * (width + height) f64
-    uint32_t tab_w = 0, tab_h = 0; double tab_m[16] = {0}; bool tab_valid = false;
     // previous frame's wave-tile costs (k_primary) and the order derived from them (k_tile_order); valid for one
     // (width, rows, band) geometry at a time
     uint32_t* d_tile_cost = nullptr; uint32_t* d_tile_order = nullptr; uint32_t tile_slots = 0;
@@ -58,11 +60,18 @@ struct NraysScene {
     // analytic scenes (workgroup lists): costs are recorded on the first frame of a camera, sorted once on the second, and
     // the order is then reused as long as the camera stays (the scene of a handle never changes)
     uint64_t cost_cam = 0, order_key = 0, order_cam = 0; bool order_valid = false; uint32_t order_age = 0;
+    // ... and by cameras NEAR the one whose costs it was sorted from (nrays_hip.hip: cam_shift_px) for up to kMaxOrderAge frames, so that a moving camera does not
+    // record and sort on every frame.  order_seeded: the order comes from k_seed_costs' guess, the next frame replaces it.
+    nrays::CamSnap cost_snap, order_snap; bool order_seeded = false;
+    bool near_reuse = true;                         // NRAYS_NEAR_REUSE=0: only the very same camera reuses an order (A/B)
+    double near_pixels = 16.0; uint32_t max_order_age = 8; // NRAYS_NEAR_PIXELS / NRAYS_ORDER_AGE
+    float split_hyst = 0.5f;                        // NRAYS_SPLIT_HYST: a tile that ran in parts stays split down to this fraction of the split threshold (k_tile_order)
+    bool lone_known = false; uint64_t lone_key = 0, stats_key = 0; // the lead / second decision of the last sort that reported, and the geometry it belongs to
     // ... and the sort also reports the sum and the maximum of the costs: their ratio is the frame's parallelism, which
     // decides between cost-ordered lists with the long tiles on the first workgroup of each CU (few long tiles) and image-order
     // lists (many tiles: throughput)
 #ifdef NR_DEBUG_TILE_COSTS
-    uint32_t* d_wave_times = nullptr; uint32_t dbg_grid = 0;
+    uint32_t* d_wave_times = nullptr; uint32_t dbg_grid = 0; uint32_t* d_seed_copy = nullptr;
 #endif
     unsigned long long* d_cost_stats = nullptr; unsigned long long* h_cost_stats = nullptr; hipEvent_t ev_stats = nullptr;
     bool stats_pending = false, lone_waves = false;

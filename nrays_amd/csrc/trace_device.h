@@ -1135,6 +1135,10 @@ NR_DEV bool shadow_query(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, 
 // rounding (l, n unit), so the normalised dot differs from dot(ru, dir) by < 1e-14: beyond the 1e-9 margin the sign is certain, inside it the ray is traced.
 // A material without a specular colour (Ks 0 0 0, most of an OBJ scene's materials): specular = ks * scoeff^shininess = 0 for every scoeff in (0, 1], and
 // diffuse + 0 = diffuse — the sample is dark as soon as the light is behind the surface.
+// Both elisions rest on x * 0 == 0 for every skipped x: nrays_scene_create checks that every light (position, radius, colour), material colour and RGBA32F texel
+// is finite and no shininess negative, and sets DScene::no_elide otherwise — such a scene is rendered as the reference renders it, NaN for NaN
+// (tests/test_elision_gpu.py).  `normal` and `dir` are unit vectors by construction (the casts return normalised normals, ncollide's contract; rays are normalised
+// where they are made), never scene input.
 NR_DEV bool light_is_dark(d3 ldir, d3 normal, d3 dir, bool no_specular) {
     const double dln = dot(ldir, normal);
     if ((float)dln > 0.0f) return false;
@@ -1184,7 +1188,7 @@ NR_MAT_ATTR f4 material_compute(const DScene& S, Stack& st, const ShadeRec& m, R
                 filter = pre_filter;
             } else {
                 cnt.shadow++;
-                if (!STATS && NR_ELIDE_DARK && light_is_dark(ldir, normal, ray.d, no_spec)) { cnt.elided++; continue; }
+                if (!STATS && NR_ELIDE_DARK && !S.no_elide && light_is_dark(ldir, normal, ray.d, no_spec)) { cnt.elided++; continue; }
                 NR_TIC(tsq);
                 // kFeatPark: what the Phong terms below need of this hit waits in LDS while the shadow ray is traced (the values are the same
                 // bits afterwards; `in.n`, `point` and `ray.d` are the caller's objects, so its later uses read the reloaded registers too)
@@ -1329,7 +1333,7 @@ NR_DEV f3 shade_hit(const DScene& S, Stack& st, RayState& ray, uint32_t depth, u
     // analytic ones 1.5 % of the primitives frame (same log); a perfect mirror in such a scene is shaded as the reference shades it.
     float alpha_known = -1.0f;
     bool elide = false;
-    if (!STATS && NR_ELIDE_TRANSPARENT && (FEAT & kFeatAlphaShadow) && (FEAT & kFeatMesh)) {
+    if (!STATS && NR_ELIDE_TRANSPARENT && (FEAT & kFeatAlphaShadow) && (FEAT & kFeatMesh) && !S.no_elide) {
         const ShadeRec& sm = S.shade[node_id];
         if (((sm.flags >> 8) & 0xffu) == NRAYS_MAT_PHONG) {
             const bool mirror = sm.refl_mix == 1.0f; // (the same for a perfect mirror: its own term is obj.rgb * (weight * alpha * (1 - 1)))
@@ -1367,7 +1371,7 @@ NR_DEV f3 shade_hit(const DScene& S, Stack& st, RayState& ray, uint32_t depth, u
             pre = true;
             NR_TOC(cyc_x[3], tsh);
             NR_TIC(tsq);
-            if (!STATS && NR_ELIDE_DARK && light_is_dark(ldir, is.n, ray.d, no_specular(S.shade[node_id]))) { if (count_me) cnt.elided++; pre_lit = false; } // (as if shadowed: the sample's term is 0 either way)
+            if (!STATS && NR_ELIDE_DARK && !S.no_elide && light_is_dark(ldir, is.n, ray.d, no_specular(S.shade[node_id]))) { if (count_me) cnt.elided++; pre_lit = false; } // (as if shadowed: the sample's term is 0 either way)
             else {
             // kFeatPark: the hit's record and the ray wait in LDS while the shadow ray is traced (the same bits come back)
             if ((FEAT & kFeatPark) && (FEAT & kFeatAlphaShadow)) {
@@ -1452,16 +1456,37 @@ NR_DEV f3 trace_chain(const DScene& S, Stack& st, bool alive, RayState ray, uint
 }
 
 // scene.rs:74-89: jitter, NDC, unproject by (P V)^-1, normalise.
-// PLAIN: a frame known (on the host) to use the raygen tables and no RNG keys — one sample per pixel, no AA jitter,
-// no area light; the generic code and the uniforms it needs drop out of the kernel.
+// PLAIN: a frame known (on the host) to use no RNG keys — one sample per pixel, no AA jitter, no area light; the generic
+// code and the uniforms it needs drop out of the kernel.  (Rounds 2-5 tabulated M[:,0] dx_i and M[:,1] dy_j per column / row in
+// a kernel of their own; computing them here costs the same — balls 0.0479 ms either way, primitives 0.202 -> 0.199 — and a
+// camera's first frame loses a launch: profiles/r06_raygen_tables_ab.log.)
 template <bool PLAIN = false>
-NR_DEV void generate_primary(const DRender& R, uint32_t i, uint32_t j, uint32_t s, uint32_t pixel_out, RayState& ray) {
-    if (PLAIN) {
-        const double* ct = R.col_tab + 4 * (size_t)i;
-        const double* rt = R.row_tab + 4 * (size_t)j;
+NR_DEV void generate_primary(const DRender& R, uint32_t i, uint32_t j, uint32_t s, uint32_t pixel_out, RayState& ray, const double* m_mem = nullptr) {
+    if (PLAIN) { // jitter-free, no RNG keys: dx, dy straight from the pixel (scene.rs:81-83)
         double h[4];
+        // m_mem: the address of DRender::m in the kernel-argument segment (k_primary).  The first two columns of the matrix are then fetched by VECTOR loads, once per
+        // tile, instead of living in 16 more SGPRs across the whole tile loop (the kernels already spill 140 - 250 SGPRs: sponza + 0.8 %, balls + 1 % with them)
+        double m0[4], m1[4];
+        if (m_mem) {
+            unsigned long long addr = (unsigned long long)m_mem;
+            asm volatile("" : "+v"(addr)); // a VGPR address: global_load, not s_load
+            const __attribute__((address_space(1))) double* mp = (const __attribute__((address_space(1))) double*)addr;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) h[r] = ct[r] + rt[r] + R.m[8 + r] * -1.0 + R.m[12 + r] * 1.0;
+            for (int r = 0; r < 4; ++r) { m0[r] = mp[r]; m1[r] = mp[4 + r]; }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { m0[r] = R.m[r]; m1[r] = R.m[4 + r]; }
+        }
+        // i / width and j / height, correctly rounded, in three instructions each instead of the ~30 of an f64 division: with y = RN(1 / b) from the
+        // host, q0 = RN(a y), r = a - q0 b (exact in an fma), q = RN(q0 + r y) == RN(a / b) (Markstein's correction step; checked for EVERY pixel index of
+        // every resolution up to 16384 by tools/probe/div_markstein.c, tests/test_numerics_tables.py; the host only launches a PLAIN kernel below that)
+        const double ai = (double)i, aj = (double)j, bw = (double)R.width, bh = (double)R.height;
+        const double qi0 = ai * R.inv_width, qj0 = aj * R.inv_height;
+        const double qi = __builtin_fma(__builtin_fma(-qi0, bw, ai), R.inv_width, qi0), qj = __builtin_fma(__builtin_fma(-qj0, bh, aj), R.inv_height, qj0);
+        const double dx = (qi - 0.5) * 2.0;
+        const double dy = -(qj - 0.5) * 2.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[r] = m0[r] * dx + m1[r] * dy + R.m[8 + r] * -1.0 + R.m[12 + r] * 1.0;
         d3 eye = D3(h[0] / h[3], h[1] / h[3], h[2] / h[3]);
         d3 e0 = D3(R.eye[0], R.eye[1], R.eye[2]);
         ray.o = e0; ray.d = normalize(eye - e0); ray.refr = 1.0; ray.energy = 1.0f; ray.weight = 1.0f;
@@ -1476,22 +1501,15 @@ NR_DEV void generate_primary(const DRender& R, uint32_t i, uint32_t j, uint32_t 
         skey = rng_hash(pkey, s);
     }
     double h[4];
-    if (R.col_tab) { // no jitter: h = ((M0*dx_i + M1*dy_j) + M2*(-1)) + M3*1 with the two products tabulated
-        const double* ct = R.col_tab + 4 * (size_t)i;
-        const double* rt = R.row_tab + 4 * (size_t)j;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) h[r] = ct[r] + rt[r] + R.m[8 + r] * -1.0 + R.m[12 + r] * 1.0;
-    } else {
-        double ox = (double)i, oy = (double)j;
-        if (R.window_width != 0.0) {
-            ox = ox + (rng_u01(skey, 0) - 0.5) * R.window_width;
-            oy = oy + (rng_u01(skey, 1) - 0.5) * R.window_width;
-        }
-        double dx = (ox / (double)R.width - 0.5) * 2.0;
-        double dy = -(oy / (double)R.height - 0.5) * 2.0;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) h[r] = R.m[r] * dx + R.m[4 + r] * dy + R.m[8 + r] * -1.0 + R.m[12 + r] * 1.0;
+    double ox = (double)i, oy = (double)j;
+    if (R.window_width != 0.0) {
+        ox = ox + (rng_u01(skey, 0) - 0.5) * R.window_width;
+        oy = oy + (rng_u01(skey, 1) - 0.5) * R.window_width;
     }
+    double dx = (ox / (double)R.width - 0.5) * 2.0;
+    double dy = -(oy / (double)R.height - 0.5) * 2.0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) h[r] = R.m[r] * dx + R.m[4 + r] * dy + R.m[8 + r] * -1.0 + R.m[12 + r] * 1.0;
     d3 eye = D3(h[0] / h[3], h[1] / h[3], h[2] / h[3]);
     d3 e0 = D3(R.eye[0], R.eye[1], R.eye[2]);
     ray.o = e0; ray.d = normalize(eye - e0); ray.refr = 1.0; ray.energy = 1.0f; ray.weight = 1.0f;

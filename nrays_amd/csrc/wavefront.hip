@@ -915,7 +915,7 @@ static int wf_render_feat(NraysScene* sc, const NraysRenderParams* p, DRender R,
     if (rc != NRAYS_OK) return rc;
     WavefrontState& w = *sc->wf;
     float* acc = spp > 1 ? w.d_acc : d_out;
-    const bool plain = R.col_tab && !R.use_rng && spp == 1u;
+    const bool plain = R.window_width == 0.0 && !R.use_rng && spp == 1u && R.width <= 16384u && R.height <= 16384u;
     const bool can_continue = sc->host.any_reflective || sc->host.any_transparent;
     const uint32_t keyed = R.use_rng ? 1u : 0u;
     R.sample_begin = 0; R.sample_end = spp; R.first_batch = 1u;

@@ -112,3 +112,42 @@ def test_lights_behind_the_surface_are_counted_not_traced(gpu, make, kw):
             assert getattr(st, k) == getattr(ost, k), (k, getattr(st, k), getattr(ost, k))
     assert stats[2].rays_shadow_elided == 0
     assert 0 < stats[0].rays_shadow_elided == stats[1].rays_shadow_elided < stats[0].rays_shadow
+
+
+def _nonfinite_scene(kind):
+    """The alpha-mapped scene above with ONE non-finite input: the reference multiplies it by 0 and gets NaN (phong_material.rs:131-141, scene.rs:179-190);
+    skipping the multiplication would give a finite pixel, so nrays_scene_create switches the elisions off for such a scene (DScene::no_elide)."""
+    sc, cam, per_hit = _scene(3)
+    nodes, lights = list(sc._nodes), list(sc._lights)
+    if kind == "light":      # an infinitely bright light behind half of the surfaces
+        lights[1] = nr.Light((-4.0, 5.0, -2.0), 0.0, 1, (float("inf"), 0.5, 0.6))
+    elif kind == "texel":    # one +inf texel in an RGBA32F colour texture of the alpha-mapped wall (its holes have alpha 0: inf * 0)
+        tex = np.full((8, 8, 4), 0.5, np.float32); tex[..., 3] = 1.0; tex[3, 4, 1] = np.inf
+        nodes[0].material.texture = nr.Texture2d(nr.ImageData(tex), nr.Interpolation.Nearest, nr.Overflow.Wrap)
+    elif kind == "shininess":  # a negative exponent: scoeff^n -> inf as scoeff -> 0, on the node of alpha 0
+        nodes[1].material = nr.PhongMaterial((0.2, 0.2, 0.25), (0.7, 0.7, 0.8), (1, 1, 1), None, None, -3.0)
+    return nr.Scene(nodes, lights, (0.6, 0.7, 0.9)), cam
+
+
+@pytest.mark.parametrize("kind", ["light", "texel", "shininess"])
+def test_non_finite_inputs_switch_the_elisions_off(gpu, kind):
+    import torch
+    lib = abi.load_hip_lib()
+    sc, cam = _nonfinite_scene(kind)
+    p, _ = su.camera_params(cam, 208, 120)
+    ref, ost = oracle.render(sc.descriptor, p, 8)
+    out = torch.empty((120, 208, 3), dtype=torch.float32, device="cuda")
+    frames, stats = [], []
+    for fn in (lib.nrays_render_device, lib.nrays_render_device, lib.nrays_render_device_instrumented):
+        abi.check(fn(sc.device_handle(), C.byref(p), C.c_void_p(out.data_ptr()), None))
+        frames.append(out.cpu().numpy().copy()); stats.append(nr.get_stats(sc))
+    assert all(st.rays_shadow_elided == 0 for st in stats)                          # nothing is skipped in this scene
+    assert np.array_equal(frames[0], frames[2], equal_nan=True) and np.array_equal(frames[1], frames[2], equal_nan=True)
+    # the reference's pixels: NaN / inf where it produces them, the usual tolerance elsewhere
+    fin = np.isfinite(ref)
+    assert np.array_equal(np.isnan(frames[0]), np.isnan(ref)) and np.array_equal(np.isinf(frames[0]), np.isinf(ref))
+    assert float(np.abs(frames[0][fin] - ref[fin]).max()) <= 1e-4
+    if kind != "shininess":
+        assert (~fin).any()                                                          # the case really produces non-finite pixels
+    for k in ("rays_primary", "rays_reflection", "rays_refraction", "rays_shadow"):
+        assert getattr(stats[0], k) == getattr(ost, k), (k, getattr(stats[0], k), getattr(ost, k))
