@@ -81,54 +81,65 @@ def camera_params(cam, W, H):
 L2_PEAK_GBS = 34500.0  # same guide, "L2 (per XCD)": 32 MiB aggregate, ~34.5 TB/s
 
 
-def roofline_block(pk, tst, W, owned_rows, scene_bytes, pmc, pmc_source, tile_costs=None, step_ms=None):
-    """Roofline of the dominant kernel (k_primary).
+def roofline_block(pk, tst, W, owned_rows, scene_bytes, pmc, pmc_source, tile_costs=None, step_ms=None, pk_ref=None):
+    """Roofline of the dominant kernel (k_primary).  ONE kernel, one set of units: `pk` holds the counters of an instrumented render that skips exactly what
+    the timed plain kernel skips (nrays_render_device_counted, NRAYS_COUNT_AS_TIMED), `pk_ref` the reference algorithm's counts (every ray scene.rs traces),
+    reported beside them as `reference_units_per_launch`.
 
-    `frac` = the LARGEST of the kernel's utilisations of real ceilings, each <= 1 by construction (VERDICT r3 item 2):
+    `frac` = the LARGEST of the kernel's utilisations of real ceilings, each <= 1 by construction:
       hbm    DRAM bytes moved (PMC FETCH_SIZE / WRITE_SIZE, the guide's gfx950 corrections) / kernel time / 8 TB/s
-      l2     bytes the waves actually request from the L2s (TCC requests x 128 B: a wave-uniform scalar node fetch is ONE
-             request, not 64) / kernel time / 34.5 TB/s
-      valu   SIMD cycles with a VALU instruction issuing (SQ_ACTIVE_INST_VALU x 4) / SIMD cycles of the kernel at 2.4 GHz
-    `bound` names that ceiling; `achieved` / `peak` / `unit` are its numbers.  The SURVEY 8(d) figure — algorithmic record
-    bytes of the tests actually run (no 64 B "ray record": rays live in registers; wave tiles decided by the screen bounds run
-    no test) / kernel time / HBM peak — is kept as `contract_*`: a rate of useful record bytes served mostly from caches, which
-    can exceed 1 and is NOT a utilisation.  `limiter` says what the schedule is waiting for (longest wave tile vs sum of tile
-    cycles per resident wave, from the library's per-tile cycle counts)."""
-    # Kernel time: HIP events around the launch (every 4th frame) also see its dispatch latency (~3 us: 50.7 us where rocprofv3 reports 46.6 and a
-    # whole step takes 49.6) — in the steady loop the dispatch of frame k + 1 hides behind frame k.  A single-launch frame's kernel cannot take
-    # longer than the step, so the fractions use min(event time, ms_per_step); `kernel_ms_events` keeps the raw figure.  The rocprofv3 average of
-    # the same kernel is in profiles/r05_rocprofv3_kernel_stats_<scene>.csv (tools/final_run.sh).
+      l2     bytes the waves request from the L2s (TCC requests x 128 B: a wave-uniform scalar node fetch is ONE request, not 64) / kernel time / 34.5 TB/s
+      valu   SIMD cycles with a VALU instruction issuing (SQ_ACTIVE_INST_VALU x 4) / SIMD cycles of the kernel at the MEASURED shader clock
+    `contract_*` = SURVEY 8(d): algorithmic record bytes of the timed kernel's tests (32 B per box per lane, ...) / kernel time / HBM peak — a rate of useful
+    bytes served mostly by caches and scalar broadcasts, not a utilisation; `unique_fetch_*` = the same with the node bytes counted as FETCHED: 128 B once
+    per wave for a wave-uniform visit, 128 B per lane otherwise (NraysStats::node_fetches) — the byte count the scalar-broadcast design is held to.
+    `limiter`: longest dealt unit and sum of tile cycles per resident wave of the cost-recording launch over THAT launch's own duration, cycles converted
+    at the clock that launch measured (NraysTileCosts::kernel_ms, shader_clock_hz): fractions of one launch, <= 1."""
+    # Kernel time: HIP events around the launch (every 4th frame) also see its dispatch latency (~3 us) — in the steady loop the dispatch of frame k + 1 hides
+    # behind frame k.  A single-launch frame's kernel cannot take longer than the step, so the fractions use min(event time, ms_per_step); `kernel_ms_events`
+    # keeps the raw figure.  The rocprofv3 average of the same kernel is in profiles/r06_rocprofv3_kernel_stats_<scene>.csv (tools/final_run.sh).
     t_events = tst.kernel_ms_primary * 1e-3
     single = abs(tst.kernel_ms_total - tst.kernel_ms_primary) <= 1e-9
     t = min(t_events, step_ms * 1e-3) if (step_ms and single and t_events > 0) else t_events
     fb = 12 * W * owned_rows
-    record_bytes = 32 * pk.node_tests + 36 * pk.tri_tests + 64 * pk.prim_tests + 64 * pk.hit_records + 16 * pk.tex_samples + fb
+    other = 36 * pk.tri_tests + 64 * pk.prim_tests + 64 * pk.hit_records + 16 * pk.tex_samples + fb
+    record_bytes = 32 * pk.node_tests + other
+    unique_bytes = 128 * pk.node_fetches + other
     contract = record_bytes / t / 1e9 if t > 0 else 0.0
+    unique = unique_bytes / t / 1e9 if t > 0 else 0.0
+    clk = tile_costs.shader_clock_hz if (tile_costs is not None and tile_costs.shader_clock_hz > 1e8) else None
+
+    def units(k):
+        return {"rays": int(k.total_rays()), "rays_traced": int(k.rays_traced()), "rays_shadow_counted_not_traced": int(k.rays_shadow_elided),
+                "node_tests": int(k.node_tests), "node_fetches_128B": int(k.node_fetches), "tri_tests": int(k.tri_tests), "prim_tests": int(k.prim_tests),
+                "hit_records": int(k.hit_records), "tex_samples": int(k.tex_samples)}
     r = {"bound": None, "contract_bound": "hbm", "kernel": "k_primary", "achieved": None, "peak": None, "unit": None, "frac": None,
          "traffic": None, "traffic_source": None, "ceilings": {},
          "contract_achieved": round(contract, 2), "contract_peak": HBM_PEAK_GBS, "contract_unit": "GB/s", "contract_frac": round(contract / HBM_PEAK_GBS, 5),
-         "algorithmic_bytes_per_launch": int(record_bytes), "kernel_ms": round(t * 1e3, 5), "kernel_ms_events": round(tst.kernel_ms_primary, 5),
+         "algorithmic_bytes_per_launch": int(record_bytes),
+         "unique_fetch_bytes_per_launch": int(unique_bytes), "unique_fetch_achieved": round(unique, 2), "unique_fetch_frac": round(unique / HBM_PEAK_GBS, 5),
+         "kernel_ms": round(t * 1e3, 5), "kernel_ms_events": round(tst.kernel_ms_primary, 5),
          "frame_gpu_ms": round(tst.kernel_ms_total, 5), "launches_timed": int(tst.frames_timed),
          "compulsory_bytes": int(scene_bytes + fb),
-         "units_per_launch": {"rays": int(pk.total_rays()), "rays_traced": int(pk.rays_traced()) - int(tst.rays_shadow_elided),
-                              "rays_shadow_counted_not_traced": int(tst.rays_shadow_elided), "node_tests": int(pk.node_tests), "tri_tests": int(pk.tri_tests),
-                              "prim_tests": int(pk.prim_tests), "hit_records": int(pk.hit_records), "tex_samples": int(pk.tex_samples)},
-         "note": "frac = max over real ceilings (hbm: PMC DRAM bytes, l2: TCC requests x 128 B, valu: VALU-issue cycles), each <= 1; "
-                 "contract_* = SURVEY 8d algorithmic record bytes (the tests of the instrumented frame, which traces every ray the reference "
-                 "traces; plain frames leave out the shadow rays whose result is multiplied by exactly 0 — light samples behind the surface, hits "
-                 "without a term of their own: rays_shadow_counted_not_traced) / kernel time / "
-                 "HBM peak (a rate of useful bytes served from caches and SGPR broadcasts, may exceed 1, not a utilisation); the kernels are latency-bound (wave_wait_frac): "
-                 "`limiter` names what the schedule waits for"}
-    if tile_costs is not None and t > 0 and tile_costs.tiles:
-        # shader cycles -> seconds at the guide's 2.4 GHz maximum (the clock under load is lower: the fractions are lower bounds)
-        longest = tile_costs.max_cycles / CLOCK_HZ
-        through = tile_costs.sum_cycles / max(tile_costs.resident_waves, 1) / CLOCK_HZ
+         "shader_clock_ghz": round(clk / 1e9, 4) if clk else None,
+         "units_per_launch": units(pk), "units_source": "instrumented render that skips what the timed kernel skips (NRAYS_COUNT_AS_TIMED)",
+         "note": "frac = max over real ceilings (hbm: PMC DRAM bytes, l2: TCC requests x 128 B, valu: VALU-issue cycles at the measured clock), each <= 1; "
+                 "contract_* = SURVEY 8d algorithmic record bytes of the TIMED kernel's own tests / kernel time / HBM peak (useful bytes served by caches and SGPR "
+                 "broadcasts: a rate, not a utilisation); unique_fetch_* = node bytes as fetched (128 B once per wave-uniform visit); reference_units_per_launch = the "
+                 "reference algorithm's counts (every shadow ray traced); the kernels are latency-bound (wave_wait_frac): `limiter` names what the schedule waits for"}
+    if pk_ref is not None:
+        r["reference_units_per_launch"] = units(pk_ref)
+    if tile_costs is not None and tile_costs.tiles and tile_costs.kernel_ms > 0 and clk:
+        tk = tile_costs.kernel_ms * 1e-3  # the recording launch's own duration
+        longest = tile_costs.max_cycles / clk
+        through = tile_costs.sum_cycles / max(tile_costs.resident_waves, 1) / clk
         lim = {"longest_tile_cycles": int(tile_costs.max_cycles), "sum_tile_cycles": int(tile_costs.sum_cycles), "wave_tiles": int(tile_costs.tiles),
-               "resident_waves": int(tile_costs.resident_waves), "longest_tile_frac": round(longest / t, 4),
-               "wave_throughput_frac": round(through / t, 4),
-               "source": "nrays_get_tile_costs: s_memtime cycles of every wave tile of this camera's cost-recording frame (a tile the cost-ordered lists split: by part)"}
+               "resident_waves": int(tile_costs.resident_waves), "recording_launch_ms": round(tile_costs.kernel_ms, 5),
+               "longest_tile_frac": round(longest / tk, 4), "wave_throughput_frac": round(through / tk, 4),
+               "source": "nrays_get_tile_costs: s_memtime cycles of every unit the cost-recording launch of this camera dealt (a split tile: by part), converted at the clock "
+                         "that launch measured, over that launch's own duration (first wave's start to last wave's end)"}
         lim["name"] = "latency/longest-tile" if longest >= through else "throughput/wave-cycles"
-        lim["frac"] = round(max(longest, through) / t, 4)
+        lim["frac"] = round(max(longest, through) / tk, 4)
         r["limiter"] = lim
     if pmc and t > 0:
         r["traffic_source"] = pmc_source
@@ -138,7 +149,7 @@ def roofline_block(pk, tst, W, owned_rows, scene_bytes, pmc, pmc_source, tile_co
             a = pmc["hbm_bytes_per_launch"] / t / 1e9
             ceil["hbm"] = {"achieved": round(a, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(min(a / HBM_PEAK_GBS, 1.0), 5)}
             r["dram_frac"] = ceil["hbm"]["frac"]
-        simd_cycles = NUM_SIMDS * t * CLOCK_HZ
+        simd_cycles = NUM_SIMDS * t * (clk or CLOCK_HZ)
         if pmc.get("TCC_HIT_sum") is not None and pmc.get("TCC_MISS_sum") is not None:
             req = pmc["TCC_HIT_sum"] + pmc["TCC_MISS_sum"]
             a = req * 128.0 / t / 1e9  # 128-byte L2 requests (MI355X_MICROARCH.md, HBM section)
@@ -147,8 +158,9 @@ def roofline_block(pk, tst, W, owned_rows, scene_bytes, pmc, pmc_source, tile_co
             r["l2_gbs"] = ceil["l2"]["achieved"]
         if pmc.get("SQ_ACTIVE_INST_VALU") is not None:  # quad-cycles summed over waves
             a = 4.0 * pmc["SQ_ACTIVE_INST_VALU"] / t
-            ceil["valu"] = {"achieved": round(a / 1e9, 2), "peak": round(NUM_SIMDS * CLOCK_HZ / 1e9, 1), "unit": "G SIMD-cycles/s with a VALU instruction issuing",
-                            "frac": round(min(4.0 * pmc["SQ_ACTIVE_INST_VALU"] / simd_cycles, 1.0), 4)}
+            ceil["valu"] = {"achieved": round(a / 1e9, 2), "peak": round(NUM_SIMDS * (clk or CLOCK_HZ) / 1e9, 1), "unit": "G SIMD-cycles/s with a VALU instruction issuing",
+                            "frac": round(min(4.0 * pmc["SQ_ACTIVE_INST_VALU"] / simd_cycles, 1.0), 4),
+                            "clock": "measured by the cost-recording launch" if clk else "the guide's 2.4 GHz maximum (no measured clock)"}
             r["valu_active_frac"] = ceil["valu"]["frac"]
         if pmc.get("SQ_WAIT_ANY") is not None and pmc.get("SQ_WAVE_CYCLES"):
             r["wave_wait_frac"] = round(pmc["SQ_WAIT_ANY"] / pmc["SQ_WAVE_CYCLES"], 4)  # share of the waves' lifetime spent in s_waitcnt
@@ -181,7 +193,7 @@ def pmc_for(workload, W, H, live):
                 return res, "live: rocprofv3 --pmc (2 passes, tools/pmc_collect.py TRAFFIC_PASSES) on tools/kbench.py --child %s in this run" % workload
         except Exception as e:  # the bench line must not depend on the profiler
             print("live PMC collection failed: %r" % (e,), file=sys.stderr)
-    for rnd in ("r05", "r04", "r03", "r02"):
+    for rnd in ("r06", "r05", "r04", "r03", "r02"):
         path = os.path.join(ROOT, "profiles", "%s_pmc_%s.json" % (rnd, workload))
         if os.path.exists(path) and (W, H) == (1920, 1080):
             try:
@@ -324,8 +336,13 @@ def single_gpu_measure(name, W, H, steps, warmup, args, pmc=True, moving=True):
     cold_walls.append(first[0])
     cold_ms = sorted(cold_walls)[len(cold_walls) // 2]
 
+    # two instrumented renders: the reference algorithm's counts (every ray scene.rs traces: rays_per_frame, the metric's rays), and the counts of the work the
+    # timed plain kernel really does (the shadow rays it skips skipped: the roofline's units)
     render_on(handle, p, True)
     st = nr.get_stats(scene)
+    pk_ref = abi.NraysStats()
+    abi.check(lib.nrays_get_primary_kernel_stats(handle, C.byref(pk_ref)))
+    abi.check(lib.nrays_render_device_counted(handle, C.byref(p), C.c_void_p(out.data_ptr()), C.c_void_p(stream), abi.COUNT_AS_TIMED))
     pk = abi.NraysStats()
     abi.check(lib.nrays_get_primary_kernel_stats(handle, C.byref(pk)))
     # (3) the contract's loop.  Untimed, before --warmup: the library settles its per-camera scheduling state in three plain
@@ -433,7 +450,7 @@ def single_gpu_measure(name, W, H, steps, warmup, args, pmc=True, moving=True):
         res["two_frames_in_flight_identical"] = bool(torch.equal(out, out2))
         del scene2
     pmc_res, src = (None, None) if (args.no_pmc or not pmc) else pmc_for(name, W, H, live=not args.replay_pmc)
-    res["roofline"] = roofline_block(pk, tst, W, H, lib.nrays_scene_device_bytes(handle), pmc_res, src, tile_costs, step_ms=res["ms_per_step"])
+    res["roofline"] = roofline_block(pk, tst, W, H, lib.nrays_scene_device_bytes(handle), pmc_res, src, tile_costs, step_ms=res["ms_per_step"], pk_ref=pk_ref)
     if not args.no_cpu_baseline:
         # bounded sample: a 64-spp 4K frame is ~200 CPU-core-minutes — the CPU leg of config 5 renders the same camera at an eighth
         # of the resolution in each direction (same scene, same samples per pixel), and says so
@@ -443,6 +460,9 @@ def single_gpu_measure(name, W, H, steps, warmup, args, pmc=True, moving=True):
             res["cpu_baseline"]["sample"] += " (the workload's camera at %dx%d)" % (cp.width, cp.height)
         res["gpu_over_cpu"] = round(res["value"] / max(res["cpu_baseline"]["value"], 1e-9), 1)  # against the `cores` the host granted
         res["gpu_over_cpu_at_full_host"] = round(res["value"] / max(res["cpu_baseline"]["value_at_full_host"], 1e-9), 1)  # against every logical CPU, balanced
+        # the same two ratios with the GPU's rate on the rays it really sent through a BVT query (the CPU port traces every ray it counts)
+        res["gpu_traced_over_cpu"] = round(res["value_traced"] / max(res["cpu_baseline"]["value"], 1e-9), 1)
+        res["gpu_traced_over_cpu_at_full_host"] = round(res["value_traced"] / max(res["cpu_baseline"]["value_at_full_host"], 1e-9), 1)
     return res
 
 
@@ -543,6 +563,7 @@ def run_single(args):
         cb = sp["cpu_baseline"]
         result["north_star_sponza"] = {"gpu_over_cpu": sp["gpu_over_cpu"], "cpu_effective_cores": cb["cores"], "cpu_threads": cb["threads"],
                                        "gpu_over_cpu_at_full_host": sp["gpu_over_cpu_at_full_host"], "cpu_logical_cpus": cb["logical_cpus"],
+                                       "gpu_traced_over_cpu": sp["gpu_traced_over_cpu"], "gpu_traced_over_cpu_at_full_host": sp["gpu_traced_over_cpu_at_full_host"],
                                        "gpu_mrays_s": sp["value"], "gpu_mrays_s_traced": sp["value_traced"], "cpu_mrays_s": cb["value"],
                                        "cpu_mrays_s_at_full_host": cb["value_at_full_host"], "target": 100.0,
                                        "note": "gpu_over_cpu is GPU vs the cpu_effective_cores the container granted; gpu_over_cpu_at_full_host is the figure for the whole host (stand-in scene, CPU port of the reference algorithm)"}
@@ -592,7 +613,7 @@ def tiled_measure(name, W, H, steps, warmup, rank, world, owners):
     tp = tiling.tile_params(full, owner0, owners, band)
     rows = lib.nrays_tile_rows(C.byref(tp))
     scratch = torch.empty((rows, W, 3), dtype=torch.float32, device="cuda")
-    abi.check(lib.nrays_render_device_instrumented(h0, C.byref(tp), C.c_void_p(scratch.data_ptr()), None))
+    abi.check(lib.nrays_render_device_counted(h0, C.byref(tp), C.c_void_p(scratch.data_ptr()), None, abi.COUNT_AS_TIMED))  # the timed tile kernel's own work
     pk = abi.NraysStats()
     abi.check(lib.nrays_get_primary_kernel_stats(h0, C.byref(pk)))
     for _ in range(4):  # plain frames: ray classes, and the per-camera scheduling state of every owner settles (see single_gpu_measure)

@@ -29,8 +29,8 @@
 extern "C" {
 #endif
 
-/* Bumped whenever the exported surface grows or a struct changes: 3 = + nrays_debug_blas_build / NraysBlasDump, nrays_multi_get_timings / NraysMultiTimings (round 4); 4 = NraysStats::rays_shadow_elided (round 5). */
-#define NRAYS_ABI_VERSION 4
+/* Bumped whenever the exported surface grows or a struct changes: 3 = + nrays_debug_blas_build / NraysBlasDump, nrays_multi_get_timings / NraysMultiTimings (round 4); 4 = NraysStats::rays_shadow_elided (round 5); 5 = NraysStats::node_fetches, nrays_render_device_counted, NraysTileCosts::shader_clock_hz / kernel_ms (round 6). */
+#define NRAYS_ABI_VERSION 5
 
 typedef enum NraysStatus {
     NRAYS_OK = 0,
@@ -193,7 +193,10 @@ typedef struct NraysStats {
                                      behind the surface (diffuse and specular coefficients both 0: phong_material.rs:109-141) and the samples of hits that
                                      contribute nothing of their own to the pixel (a fully transparent point: opacity-map texel 0 or node alpha 0; a perfect
                                      mirror: scene.rs:179-190).  Counted, so that rays_shadow stays the reference's number, but not traced by plain
-                                     renders; instrumented renders trace them: 0 */
+                                     renders; instrumented renders trace them: 0 (NRAYS_COUNT_AS_TIMED: they skip them like a plain render and report them here) */
+    uint64_t node_fetches;        /* instrumented renders only: 128-byte BVH node records fetched — ONE per wave for a visit in which every active lane sits on the same
+                                     node with the same direction signs (the kernels read it through the scalar unit and broadcast), one per lane otherwise.
+                                     node_fetches * 128 is the traversal's unique node traffic; node_tests * 32 counts a box per lane whoever fetched it */
 } NraysStats;
 
 /* Threading contract of a scene handle: the library is re-entrant on DISTINCT handles (any threads, any streams).
@@ -228,6 +231,13 @@ int nrays_render_device(NraysScene* scene, const NraysRenderParams* params, floa
 int nrays_render_device_instrumented(NraysScene* scene, const NraysRenderParams* params,
                                      float* out_rgb_device, void* hip_stream);
 
+/* As nrays_render_device_instrumented, with a choice of WHAT is counted.  flags = 0: the reference algorithm — every ray scene.rs / phong_material.rs trace is traced
+ * and counted.  NRAYS_COUNT_AS_TIMED: the work of the PLAIN (timed) render of this scene — the shadow rays whose result is multiplied by exactly 0 are skipped as the
+ * plain kernels skip them (and reported in rays_shadow_elided), so that node / triangle / hit / texture counts are those of the kernel whose time a roofline divides by
+ * (bench.py: roofline_block).  Pixels are the same either way. */
+#define NRAYS_COUNT_AS_TIMED 1u
+int nrays_render_device_counted(NraysScene* scene, const NraysRenderParams* params, float* out_rgb_device, void* hip_stream, uint32_t flags);
+
 /* Number of rows in the compact output buffer of a (possibly tiled) render. */
 uint32_t nrays_tile_rows(const NraysRenderParams* params);
 
@@ -253,6 +263,10 @@ typedef struct NraysTileCosts {
     uint64_t sum_cycles;     /* shader cycles (s_memtime) the waves spend on them (every part of a tile the cost-ordered lists split counted) */
     uint64_t max_cycles;     /* the longest unit the schedule deals: a tile, or ONE PART of a split tile (light-parallel / pixel-split parts) */
     uint64_t resident_waves; /* waves of the persistent grid that rendered the frame */
+    double shader_clock_hz;  /* the clock those cycles tick at, MEASURED by the launches that recorded them: s_memtime over s_memrealtime (100 MHz), summed over the
+                                lifetimes of all their waves */
+    double kernel_ms;        /* duration of that launch: first wave's start to the last wave's end (s_memrealtime).  max_cycles / shader_clock_hz and
+                                sum_cycles / resident_waves / shader_clock_hz are both <= kernel_ms: units and time come from the same launch */
 } NraysTileCosts;
 int nrays_get_tile_costs(NraysScene* scene, NraysTileCosts* out);
 

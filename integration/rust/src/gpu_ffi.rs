@@ -4,7 +4,7 @@
 
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const NRAYS_ABI_VERSION: u32 = 4; // include/nrays_abi.h; GpuScene::new refuses a library built from another header
+pub const NRAYS_ABI_VERSION: u32 = 5; // include/nrays_abi.h; GpuScene::new refuses a library built from another header
 pub const NRAYS_OK: c_int = 0;
 pub const NRAYS_ERR_BAD_ARG: c_int = -1;
 pub const NRAYS_ERR_HIP: c_int = -2;
@@ -157,6 +157,7 @@ pub struct NraysStats {
     pub reserved: u32,
     pub rays_primary_traced: u64,
     pub rays_shadow_elided: u64,
+    pub node_fetches: u64,
 }
 
 #[repr(C)]
@@ -166,6 +167,8 @@ pub struct NraysTileCosts {
     pub sum_cycles: u64,
     pub max_cycles: u64,
     pub resident_waves: u64,
+    pub shader_clock_hz: f64,
+    pub kernel_ms: f64,
 }
 
 #[repr(C)]
@@ -208,6 +211,7 @@ extern "C" {
     pub fn nrays_render_rgb8(scene: *mut NraysScene, params: *const NraysRenderParams, out_rgb8: *mut u8) -> c_int;
     pub fn nrays_render_device(scene: *mut NraysScene, params: *const NraysRenderParams, out_rgb_device: *mut f32, hip_stream: *mut c_void) -> c_int;
     pub fn nrays_render_device_instrumented(scene: *mut NraysScene, params: *const NraysRenderParams, out_rgb_device: *mut f32, hip_stream: *mut c_void) -> c_int;
+    pub fn nrays_render_device_counted(scene: *mut NraysScene, params: *const NraysRenderParams, out_rgb_device: *mut f32, hip_stream: *mut c_void, flags: u32) -> c_int;
     pub fn nrays_tile_rows(params: *const NraysRenderParams) -> u32;
     pub fn nrays_untile_device(gathered: *const f32, out_rgb_device: *mut f32, width: u32, height: u32, band_rows: u32, band_owners: u32, hip_stream: *mut c_void) -> c_int;
     pub fn nrays_get_stats(scene: *mut NraysScene, out_stats: *mut NraysStats) -> c_int;

@@ -6,7 +6,8 @@ and types must match include/nrays_abi.h exactly (tests/test_abi.py checks sizes
 import ctypes as C
 import os
 
-ABI_VERSION = 4
+ABI_VERSION = 5
+COUNT_AS_TIMED = 1  # nrays_render_device_counted: count the work of the plain (timed) render, include/nrays_abi.h
 
 # NraysStatus
 OK = 0
@@ -76,7 +77,7 @@ class NraysStats(C.Structure):
                 ("prim_tests", C.c_uint64), ("hit_records", C.c_uint64), ("tex_samples", C.c_uint64),
                 ("generations", C.c_uint32), ("instrumented", C.c_uint32), ("kernel_ms_primary", C.c_double),
                 ("kernel_ms_total", C.c_double), ("frames_timed", C.c_uint32), ("reserved", C.c_uint32),
-                ("rays_primary_traced", C.c_uint64), ("rays_shadow_elided", C.c_uint64)]
+                ("rays_primary_traced", C.c_uint64), ("rays_shadow_elided", C.c_uint64), ("node_fetches", C.c_uint64)]
 
     def rays_traced(self):
         """Rays that went through a BVT query (total_rays() counts every primary ray the reference would trace)."""
@@ -100,7 +101,7 @@ class NraysMultiTimings(C.Structure):
 
 
 class NraysTileCosts(C.Structure):
-    _fields_ = [("tiles", C.c_uint64), ("sum_cycles", C.c_uint64), ("max_cycles", C.c_uint64), ("resident_waves", C.c_uint64)]
+    _fields_ = [("tiles", C.c_uint64), ("sum_cycles", C.c_uint64), ("max_cycles", C.c_uint64), ("resident_waves", C.c_uint64), ("shader_clock_hz", C.c_double), ("kernel_ms", C.c_double)]
 
 
 class NraysCastResult(C.Structure):
@@ -125,6 +126,7 @@ HIP_SYMBOLS = {
     "nrays_render_rgb8": (C.c_int, [C.c_void_p, C.POINTER(NraysRenderParams), C.POINTER(C.c_uint8)]),
     "nrays_render_device": (C.c_int, [C.c_void_p, C.POINTER(NraysRenderParams), C.c_void_p, C.c_void_p]),
     "nrays_render_device_instrumented": (C.c_int, [C.c_void_p, C.POINTER(NraysRenderParams), C.c_void_p, C.c_void_p]),
+    "nrays_render_device_counted": (C.c_int, [C.c_void_p, C.POINTER(NraysRenderParams), C.c_void_p, C.c_void_p, C.c_uint32]),
     "nrays_tile_rows": (C.c_uint32, [C.POINTER(NraysRenderParams)]),
     "nrays_untile_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),
     "nrays_get_stats": (C.c_int, [C.c_void_p, C.POINTER(NraysStats)]),

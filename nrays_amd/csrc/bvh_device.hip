@@ -17,7 +17,6 @@
 // min / max / counts are exact and the costs are evaluated with the host's f32 operations (-ffp-contract=off), so from the same
 // references both builders produce the same tree (tests/test_device_build_gpu.py compares the node arrays).
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <chrono>
@@ -452,6 +451,51 @@ __global__ __launch_bounds__(256) void k_select(const Task* tasks, uint32_t nt, 
     }
 }
 
+// Exclusive prefix sum of n 32-bit counts (the per-triangle reference counts of the pre-splitting passes) in three launches: k_scan_sums (one sum per block of
+// kScanBlock items), k_scan_blocks (ONE workgroup scans the block sums in place), k_scan_apply (every block scans its items from its base).  A thread owns 16
+// consecutive items; the block's 256 thread sums are scanned through LDS.  Wrap-around arithmetic like any u32 sum (the caller bounds the total).
+constexpr uint32_t kScanItems = 16u, kScanBlock = 256u * kScanItems;
+__global__ __launch_bounds__(256) void k_scan_sums(const uint32_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ block_sum) {
+    __shared__ uint32_t s_w[4];
+    const uint32_t base = blockIdx.x * kScanBlock + threadIdx.x * kScanItems;
+    uint32_t sum = 0;
+    for (uint32_t k = 0; k < kScanItems; ++k) if (base + k < n) sum += in[base + k];
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off);
+    if (lane_id() == 0) s_w[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) block_sum[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+__global__ __launch_bounds__(1024) void k_scan_blocks(uint32_t* block_sum, uint32_t nb) { // in place: block_sum[b] becomes the sum of the blocks before b
+    __shared__ uint32_t s_sum[1024];
+    const uint32_t per = (nb + 1023u) / 1024u, lo = threadIdx.x * per, hi = min(nb, lo + per);
+    uint32_t sum = 0;
+    for (uint32_t b = lo; b < hi; ++b) sum += block_sum[b];
+    s_sum[threadIdx.x] = sum;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024u; off <<= 1) { uint32_t v = threadIdx.x >= off ? s_sum[threadIdx.x - off] : 0u; __syncthreads(); s_sum[threadIdx.x] += v; __syncthreads(); }
+    uint32_t run = s_sum[threadIdx.x] - sum;
+    for (uint32_t b = lo; b < hi; ++b) { const uint32_t v = block_sum[b]; block_sum[b] = run; run += v; }
+}
+__global__ __launch_bounds__(256) void k_scan_apply(const uint32_t* __restrict__ in, uint32_t n, const uint32_t* __restrict__ block_base, uint32_t* __restrict__ out) {
+    __shared__ uint32_t s_t[256];
+    const uint32_t base = blockIdx.x * kScanBlock + threadIdx.x * kScanItems;
+    uint32_t v[kScanItems], sum = 0;
+    for (uint32_t k = 0; k < kScanItems; ++k) { v[k] = base + k < n ? in[base + k] : 0u; sum += v[k]; }
+    s_t[threadIdx.x] = sum;
+    __syncthreads();
+    for (uint32_t off = 1; off < 256u; off <<= 1) { uint32_t q = threadIdx.x >= off ? s_t[threadIdx.x - off] : 0u; __syncthreads(); s_t[threadIdx.x] += q; __syncthreads(); }
+    uint32_t run = block_base[blockIdx.x] + s_t[threadIdx.x] - sum;
+    for (uint32_t k = 0; k < kScanItems; ++k) { if (base + k < n) out[base + k] = run; run += v[k]; }
+}
+static hipError_t exclusive_scan_u32(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* block_tmp) {
+    const uint32_t nb = (n + kScanBlock - 1u) / kScanBlock;
+    if (nb == 0u) return hipSuccess;
+    hipLaunchKernelGGL(k_scan_sums, dim3(nb), dim3(256), 0, 0, in, n, block_tmp);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, 0, block_tmp, nb);
+    hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, 0, in, n, block_tmp, out);
+    return hipGetLastError();
+}
+
 // lefts[c] = references of chunk c that go left (from the chunk's own bin counts: no pass over the references).
 __global__ __launch_bounds__(256) void k_chunk_lefts(const uint32_t* chunk_task, const uint32_t* chunk_cnt, const SplitInfo* split, uint32_t nchunks, uint32_t* lefts) {
     const uint32_t c = blockIdx.x * 256u + threadIdx.x;
@@ -842,10 +886,9 @@ int build_impl(const std::vector<DeviceMeshPart>& parts, const DeviceBuildOption
     // the per-thread stacks of k_presplit (0.9 GB from 131 k triangles on) exist only if pre-splitting can run at all
     const bool may_split = opt.presplit && n >= 64 && opt.budget > 0.0;
     const size_t frame_count = may_split ? (size_t)split_grid * 256u * (kSplitDepthMax + 1) : 1u;
-    size_t cub_bytes = 0; // what the prefix sum over the per-triangle reference counts needs
-    DB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, cub_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)(n + 1)));
+    const size_t scan_bytes = ((n + 1 + kScanBlock - 1) / kScanBlock) * sizeof(uint32_t); // block sums of the prefix sum over the per-triangle reference counts (exclusive_scan_u32)
     bytes1 += padded<TriRec>(n) + padded<TriUv>(n) + padded<float>(6 * n) + 2 * padded<double>(nblocks_tri) + padded<Counters>(1) + 2 * padded<uint32_t>(n + 1) +
-              padded<uint32_t>(kHistBins) + padded<SplitFrame>(frame_count) + padded<char>(cub_bytes) + padded<PartDev>(parts.size()) + 4096;
+              padded<uint32_t>(kHistBins) + padded<SplitFrame>(frame_count) + padded<char>(scan_bytes) + padded<PartDev>(parts.size()) + 4096;
     DB_TRY(a1.reserve(bytes1));
     sw.lap("allocation (phase 1)");
     {   // A merged group (the sponza stand-in: 270 meshes under one isometry, ~800 small arrays) paid one synchronous hipMemcpy per array — 4-5 ms of
@@ -885,9 +928,9 @@ int build_impl(const std::vector<DeviceMeshPart>& parts, const DeviceBuildOption
     Counters* ctr = a1.take<Counters>(1);
     uint32_t* counts = a1.take<uint32_t>(n + 1); uint32_t* offsets = a1.take<uint32_t>(n + 1); uint32_t* hist = a1.take<uint32_t>(kHistBins);
     SplitFrame* frames = a1.take<SplitFrame>(frame_count);
-    void* cub_tmp1 = a1.take<char>(cub_bytes + 16);
+    void* scan_tmp1 = a1.take<char>(scan_bytes + 16);
     PartDev* dparts = a1.take<PartDev>(parts.size());
-    if (!frames || !cub_tmp1 || !dparts) { err = "device BLAS build: arena overflow (phase 1)"; return NRAYS_ERR_OOM; }
+    if (!frames || !scan_tmp1 || !dparts) { err = "device BLAS build: arena overflow (phase 1)"; return NRAYS_ERR_OOM; }
     sw.lap("upload of the mesh arrays");
     Counters h_ctr; std::memset(&h_ctr, 0, sizeof h_ctr);
     for (int k = 0; k < 6; ++k) { h_ctr.bounds[k] = 0xffffffffu; h_ctr.bounds[6 + k] = 0u; }
@@ -939,8 +982,7 @@ int build_impl(const std::vector<DeviceMeshPart>& parts, const DeviceBuildOption
             DB_TRY(hipMemset(hist, 0, kHistBins * sizeof(uint32_t)));
             DB_TRY(hipMemset(capped, 0, 4));
             hipLaunchKernelGGL(k_presplit<kModeHist>, dim3(split_grid), dim3(256), 0, 0, recs, tbox, (uint32_t)n, t, cap, frames, counts, offsets, hist, (float*)nullptr, (uint32_t*)nullptr, capped);
-            size_t tmp_bytes = cub_bytes;
-            DB_TRY(hipcub::DeviceScan::ExclusiveSum(cub_tmp1, tmp_bytes, counts, offsets, (int)(n + 1)));
+            DB_TRY(exclusive_scan_u32(counts, offsets, (uint32_t)(n + 1), (uint32_t*)scan_tmp1));
             DB_TRY(hipMemcpy(&extra, offsets + n, 4, hipMemcpyDeviceToHost));
             return NRAYS_OK;
         };

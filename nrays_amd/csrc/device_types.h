@@ -143,6 +143,7 @@ struct DeviceCounters {
     unsigned int pad0;
     unsigned long long shadow_elided; // shadow rays counted in rays_shadow but not traced (64 bits like rays_shadow, which contains them: a 4K frame with 256 samples and 8 lights passes 2^32): light samples
                                       // behind the surface, hits on fully transparent / perfectly mirroring points (trace_device.h: light_is_dark, shade_hit)
+    unsigned long long node_fetches; // instrumented: 128-byte node records fetched, one per wave for a wave-uniform visit, one per lane otherwise
     unsigned long long dbg2[8];   // tuning builds (NR_PHASE_TIMING): wave cycles outside the queries — dequeue wait, raygen + root test, hit reconstruction + gates, shadow-ray set-up, material, weights + continuation, pixel write
     unsigned long long dbg[8];    // tuning builds (NR_PHASE_TIMING): wave / lane iteration counts of the node loops and triangle leaves, cycles per query class, wave-uniform node iterations
 };
@@ -184,6 +185,8 @@ struct DScene {
     uint32_t num_lights;
     float background[3];
     uint32_t incoherent;          // some mesh is hair-like (kInstIncoherent): traverse() ends node phases by quorum
+    uint32_t stats_elide;         // instrumented renders (set per launch): bit 0 = skip dark light samples, bit 1 = skip the shading of hits without a term of their own, as the
+                                  // scene's PLAIN kernel does (NRAYS_COUNT_AS_TIMED); 0 = trace everything the reference traces
     uint32_t no_elide;            // some light / material / RGBA32F texel of the scene is not finite (or a shininess is negative): x * 0 is then not 0 for every x the
                                   // reference multiplies, so NO shadow ray or Phong evaluation is skipped (light_is_dark(), shade_hit()); nrays_scene_create decides
     // Small analytic scenes (no meshes; all records below within kLdsSceneBytes): one packed copy of nodes, instances,
@@ -229,6 +232,11 @@ struct DRender {
     // Mesh scenes (dynamic dequeue): per-wave-tile cost of this frame (written) and the wave tiles in
     // descending order of the previous frame's cost (read; null = image order).  Scheduling only.
     uint32_t* tile_cost;
+    // ... and, with it, four words about the recording launch itself (nrays_get_tile_costs): [0] 100 MHz tick (s_memrealtime) at which its first wave started, [1] latest tick at
+    // which one of its waves ended (atomicMax: the counter is monotonic, no clearing), [2] shader cycles (s_memtime) and [3] ticks of ALL wave lifetimes, summed over the
+    // handle's recording launches (never cleared: the ratio is the clock the waves ran at, weighted by wave time) — the launch's duration and the clock its cycle counts
+    // tick at, measured by the launches that produced them
+    unsigned long long* cost_meta;
 #ifdef NR_DEBUG_TILE_COSTS
     uint32_t dbg_mode;    // tuning builds: 1 = wave_times[1] holds the wave's work-tile cycles / 16 (26 bits) and its number of work tiles (6 bits)
     uint32_t* wave_times; // tuning builds: per wave {kernel entry, first tile, exit} in 10 ns ticks (s_memrealtime) and its tile count

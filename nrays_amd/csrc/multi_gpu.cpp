@@ -534,7 +534,7 @@ int nrays_multi_get_stats(NraysSceneSet* s, NraysStats* out) {
         if (rc != NRAYS_OK) return rc;
         out->rays_primary += st.rays_primary; out->rays_reflection += st.rays_reflection; out->rays_refraction += st.rays_refraction;
         out->rays_shadow += st.rays_shadow; out->node_tests += st.node_tests; out->tri_tests += st.tri_tests; out->prim_tests += st.prim_tests;
-        out->hit_records += st.hit_records; out->tex_samples += st.tex_samples; out->rays_primary_traced += st.rays_primary_traced; out->rays_shadow_elided += st.rays_shadow_elided;
+        out->hit_records += st.hit_records; out->tex_samples += st.tex_samples; out->rays_primary_traced += st.rays_primary_traced; out->rays_shadow_elided += st.rays_shadow_elided; out->node_fetches += st.node_fetches;
         out->generations = std::max(out->generations, st.generations);
         if (k == 0) { out->kernel_ms_primary = st.kernel_ms_primary; out->kernel_ms_total = st.kernel_ms_total; out->frames_timed = st.frames_timed; out->instrumented = st.instrumented; }
     }

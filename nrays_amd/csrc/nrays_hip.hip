@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(kBlock, NRAYS_WAVES_PER_SIMD) k_bounce(DScene 
     st.lds0 = Stack::addr((lds_u32*)lds_stack);
     st.park = nullptr;
     st.init();
-    Cnt cnt; cnt.node = cnt.tri = cnt.prim = cnt.hit = cnt.tex = cnt.shadow = cnt.refl = cnt.refr = cnt.max_depth = cnt.max_chain_nodes = cnt.traced = cnt.elided = 0;
+    Cnt cnt; cnt.node = cnt.tri = cnt.prim = cnt.hit = cnt.tex = cnt.shadow = cnt.refl = cnt.refr = cnt.max_depth = cnt.max_chain_nodes = cnt.traced = cnt.elided = cnt.fetch = 0;
 #ifdef NR_PHASE_TIMING
     cnt.cyc_node = cnt.cyc_leaf = cnt.cyc_other = cnt.cyc_tri = 0; cnt.wv_node = cnt.ln_node = cnt.wv_tri = cnt.ln_tri = 0; cnt.cyc_closest0 = cnt.cyc_closestN = cnt.cyc_shadow = 0; cnt.wv_uni = 0; cnt.inq_node = cnt.inq_tri = 0; for (int k_ = 0; k_ < 8; ++k_) cnt.cyc_x[k_] = 0;
 #endif
@@ -105,7 +105,7 @@ __global__ void __launch_bounds__(kBlock, NRAYS_WAVES_PER_SIMD) k_cast_batch(DSc
     st.lds0 = Stack::addr((lds_u32*)lds_stack);
     st.park = nullptr;
     st.init();
-    Cnt cnt; cnt.node = cnt.tri = cnt.prim = cnt.hit = cnt.tex = cnt.shadow = cnt.refl = cnt.refr = cnt.max_depth = cnt.max_chain_nodes = cnt.traced = cnt.elided = 0;
+    Cnt cnt; cnt.node = cnt.tri = cnt.prim = cnt.hit = cnt.tex = cnt.shadow = cnt.refl = cnt.refr = cnt.max_depth = cnt.max_chain_nodes = cnt.traced = cnt.elided = cnt.fetch = 0;
 #ifdef NR_PHASE_TIMING
     cnt.cyc_node = cnt.cyc_leaf = cnt.cyc_other = cnt.cyc_tri = 0; cnt.wv_node = cnt.ln_node = cnt.wv_tri = cnt.ln_tri = 0; cnt.cyc_closest0 = cnt.cyc_closestN = cnt.cyc_shadow = 0; cnt.wv_uni = 0; cnt.inq_node = cnt.inq_tri = 0; for (int k_ = 0; k_ < 8; ++k_) cnt.cyc_x[k_] = 0;
 #endif
@@ -457,6 +457,12 @@ static uint32_t tile_rows(const NraysRenderParams* p) {
 // The primary kernel is instantiated per feature set (primary_kernel.h: NR_PRIMARY_PERMUTATIONS, one translation unit per group);
 // instrumented renders and k_bounce use the full-featured code (their results are identical, only slower).  The frame names the
 // permutations it could run, most specialised first; the first one the library holds is launched (a tuning build holds few).
+static bool primary_permutation_exists(int feat) { // (of the full build; a tuning build, NR_ONLY, may fall back to the full kernel)
+#define X(G, S, F, P, O) if (!S && (F & ~(int)kFeatLdsScene) == feat) return true;
+    NR_PRIMARY_PERMUTATIONS(X)
+#undef X
+    return false;
+}
 static void launch_primary(bool instrumented, int features, bool noxform, bool park, int occ, uint32_t grid, hipStream_t stream, const DScene& d, const DRender& R,
                            const QueueOut& qo, float* out, DeviceCounters* ctr, uint32_t* spill, uint32_t tx, uint32_t ty, uint32_t* work, uint32_t grab,
                            uint32_t* zero_counts, DeviceCounters* zero_ctr) {
@@ -496,7 +502,7 @@ static int alloc_cost_stats(NraysScene* sc) {
     return NRAYS_OK;
 }
 
-static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out, hipStream_t stream, bool instrumented) {
+static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out, hipStream_t stream, bool instrumented, uint32_t count_flags = 0u) {
     if (!sc || !p || !d_out) return fail(NRAYS_ERR_BAD_ARG, "null argument");
     if (p->ray_per_pixel == 0) return fail(NRAYS_ERR_BAD_ARG, "ray_per_pixel must be > 0 (scene.rs:37)");
     if (p->width == 0 || p->height == 0) return fail(NRAYS_ERR_BAD_ARG, "empty resolution");
@@ -783,7 +789,7 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
     HIP_TRY(hipMemsetAsync(sc->d_wave_times, 0, (size_t)kMaxGrid * (kBlock / 64) * 8 * sizeof(uint32_t), stream));
     R.wave_times = sc->d_wave_times; sc->dbg_grid = grid_primary; R.dbg_mode = getenv("NRAYS_DEBUG_WAVE_WORK") ? (uint32_t)atoi(getenv("NRAYS_DEBUG_WAVE_WORK")) : 0u;
 #endif
-    if (R.tile_cost) { sc->cost_tiles = lane_log2 ? win_units : win_units * 4u; sc->cost_grid = grid_primary; sc->cost_split_lsl = R.light_lsl; }
+    if (R.tile_cost) { sc->cost_tiles = lane_log2 ? win_units : win_units * 4u; sc->cost_grid = grid_primary; sc->cost_split_lsl = R.light_lsl; R.cost_meta = sc->d_cost_meta; }
     bool first_primary = true;
     for (uint32_t s0 = 0; s0 < p->ray_per_pixel; s0 += batch) {
         R.sample_begin = s0; R.sample_end = std::min<uint32_t>(p->ray_per_pixel, s0 + batch);
@@ -794,7 +800,12 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
         QueueOut qo; qo.q = sc->queue[1].q; qo.capacity = queued ? sc->queue_capacity : 0; qo.count = sc->d_counts + 1;
         qo.overflow = &sc->d_counters->overflow;
         if (first_primary && timed) HIP_TRY(hipEventRecord(sc->ev_pbegin[slot], stream));
-        launch_primary(instrumented, sc->features, sc->noxform, sc->park, occ, grid_primary, stream, sc->d, R, qo, d_out, sc->d_counters, sc->d_spill, tiles_x, tiles_y, sc->d_counts + kMaxGenerations + 2, grab, next_counts, R.first_batch ? next_ctr : nullptr);
+        DScene dsc = sc->d;
+        if (instrumented && (count_flags & NRAYS_COUNT_AS_TIMED)) { // what the scene's plain kernel skips (trace_device.h: light_is_dark everywhere; shade_hit in the alpha-mapped mesh kernels)
+            const int f = primary_permutation_exists(sc->features & ~(int)kFeatLdsScene) ? sc->features : (int)kFeatAll; // the FEAT a plain frame of this scene is launched with
+            dsc.stats_elide = 1u | (((f & kFeatMesh) && (f & kFeatAlphaShadow)) ? 2u : 0u);
+        }
+        launch_primary(instrumented, sc->features, sc->noxform, sc->park, occ, grid_primary, stream, dsc, R, qo, d_out, sc->d_counters, sc->d_spill, tiles_x, tiles_y, sc->d_counts + kMaxGenerations + 2, grab, next_counts, R.first_batch ? next_ctr : nullptr);
         HIP_TRY(hipGetLastError());
         if (first_primary) {
             if (timed) HIP_TRY(hipEventRecord(sc->ev_pend[slot], stream));
@@ -817,7 +828,7 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
             uint32_t grid = std::max<uint32_t>(std::min<uint32_t>((launch_n + kBlock - 1) / kBlock, kMaxGrid), std::min<uint32_t>((uint32_t)sc->num_cus, kMaxGrid));
             QueueOut qn; qn.q = sc->queue[(r + 1) & 1].q; qn.capacity = sc->queue_capacity; qn.count = sc->d_counts + r + 1;
             qn.overflow = &sc->d_counters->overflow;
-            if (instrumented) hipLaunchKernelGGL(k_bounce<true>, dim3(grid), dim3(kBlock), 0, stream, sc->d, sc->queue[r & 1].q, sc->d_counts + r, sc->queue_capacity, qn, sc->d_fixed, sc->d_counters, sc->d_spill, p->max_depth);
+            if (instrumented) hipLaunchKernelGGL(k_bounce<true>, dim3(grid), dim3(kBlock), 0, stream, dsc, sc->queue[r & 1].q, sc->d_counts + r, sc->queue_capacity, qn, sc->d_fixed, sc->d_counters, sc->d_spill, p->max_depth);
             else hipLaunchKernelGGL(k_bounce<false>, dim3(grid), dim3(kBlock), 0, stream, sc->d, sc->queue[r & 1].q, sc->d_counts + r, sc->queue_capacity, qn, sc->d_fixed, sc->d_counters, sc->d_spill, p->max_depth);
             HIP_TRY(hipGetLastError());
             folded = false; sc->fixed_dirty = true;
@@ -1081,6 +1092,8 @@ int nrays_scene_create(const NraysSceneDesc* desc, NraysScene** out_scene) {
             return bail(fail(NRAYS_ERR_HIP, "counter memset failed"));
     }
     sc->d_counts = sc->d_counts_set[0]; sc->d_counters = sc->d_counters_set[0];
+    if (hipMalloc((void**)&sc->d_cost_meta, 4 * sizeof(unsigned long long)) != hipSuccess || hipMemset(sc->d_cost_meta, 0, 4 * sizeof(unsigned long long)) != hipSuccess)
+        return bail(fail(NRAYS_ERR_OOM, "cost-meta allocation failed"));
     stage("records, switches, counters");
     if (hipMalloc((void**)&sc->d_counters_primary, sizeof(DeviceCounters)) != hipSuccess)
         return bail(fail(NRAYS_ERR_OOM, "counter allocation failed"));
@@ -1126,6 +1139,7 @@ void nrays_scene_destroy(NraysScene* sc) {
     if (sc->d_tile_order) (void)hipFree(sc->d_tile_order);
     if (sc->d_order_len) (void)hipFree(sc->d_order_len);
     if (sc->d_cost_stats) (void)hipFree(sc->d_cost_stats);
+    if (sc->d_cost_meta) (void)hipFree(sc->d_cost_meta);
     if (sc->d_rgb8) (void)hipFree(sc->d_rgb8);
     if (sc->h_cost_stats) (void)hipHostFree(sc->h_cost_stats);
     if (sc->ev_stats) (void)hipEventDestroy(sc->ev_stats);
@@ -1150,10 +1164,15 @@ int nrays_render_device_instrumented(NraysScene* scene, const NraysRenderParams*
     return render_impl(scene, params, out_rgb_device, (hipStream_t)hip_stream, true);
 }
 
+int nrays_render_device_counted(NraysScene* scene, const NraysRenderParams* params, float* out_rgb_device, void* hip_stream, uint32_t flags) {
+    if (flags & ~NRAYS_COUNT_AS_TIMED) return fail(NRAYS_ERR_BAD_ARG, "unknown count flags");
+    return render_impl(scene, params, out_rgb_device, (hipStream_t)hip_stream, true, flags);
+}
+
 static void fill_counters(NraysStats* out, const DeviceCounters& c) {
     out->rays_reflection = c.rays_reflection; out->rays_refraction = c.rays_refraction; out->rays_shadow = c.rays_shadow;
     out->node_tests = c.node_tests; out->tri_tests = c.tri_tests; out->prim_tests = c.prim_tests;
-    out->hit_records = c.hit_records; out->tex_samples = c.tex_samples; out->rays_primary_traced = c.rays_primary_traced;
+    out->hit_records = c.hit_records; out->tex_samples = c.tex_samples; out->rays_primary_traced = c.rays_primary_traced; out->node_fetches = c.node_fetches;
 }
 
 int nrays_get_stats(NraysScene* sc, NraysStats* out) {
@@ -1206,6 +1225,12 @@ int nrays_get_tile_costs(NraysScene* sc, NraysTileCosts* out) {
         out->sum_cycles += unit * n * 16u; out->max_cycles = std::max<uint64_t>(out->max_cycles, unit * 16u);
     }
     out->tiles = c.size(); out->resident_waves = (uint64_t)sc->cost_grid * (kBlock / 64);
+    if (sc->d_cost_meta) { // the recording launch about itself (DRender::cost_meta)
+        unsigned long long m[4] = {0, 0, 0, 0};
+        HIP_TRY(hipMemcpy(m, sc->d_cost_meta, sizeof m, hipMemcpyDeviceToHost));
+        out->shader_clock_hz = m[3] ? (double)m[2] / ((double)m[3] * 1e-8) : 0.0;
+        out->kernel_ms = m[1] > m[0] ? (double)(m[1] - m[0]) * 1e-5 : 0.0;
+    }
     return NRAYS_OK;
 }
 
@@ -1272,6 +1297,7 @@ int nrays_get_primary_kernel_stats(NraysScene* sc, NraysStats* out) {
     HIP_TRY(hipMemcpy(&c, sc->d_counters_primary, sizeof c, hipMemcpyDeviceToHost));
     out->rays_primary = sc->last_primary_first_batch;
     fill_counters(out, c);
+    out->rays_shadow_elided = c.shadow_elided;
     // single continuations (reflection OR refraction) are traced by the primary kernel itself (trace_chain); only the
     // second child of a double branch goes through the queue to k_bounce, after this snapshot was taken
     out->instrumented = 1;

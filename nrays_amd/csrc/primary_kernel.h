@@ -57,13 +57,13 @@ __device__ __forceinline__ uint32_t issue_grab(uint32_t* work_counters, uint32_t
 __device__ __forceinline__ void flush_counters(DeviceCounters* ctr, const Cnt& c, bool stats) {
     // wave-level reduction, then one atomic per wave and class
     unsigned sh = c.shadow, rl = c.refl, rf = c.refr, md = c.max_depth, mc = c.max_chain_nodes, el = c.elided;
-    unsigned nd = c.node, tr = c.tri, pr = c.prim, ht = c.hit, tx = c.tex, tc = c.traced;
+    unsigned nd = c.node, tr = c.tri, pr = c.prim, ht = c.hit, tx = c.tex, tc = c.traced, nf = c.fetch;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         sh += __shfl_down(sh, off); rl += __shfl_down(rl, off); rf += __shfl_down(rf, off); el += __shfl_down(el, off);
         unsigned om = __shfl_down(md, off); md = om > md ? om : md;
         if (stats) { unsigned oc = __shfl_down(mc, off); mc = oc > mc ? oc : mc; }
-        if (stats) { nd += __shfl_down(nd, off); tr += __shfl_down(tr, off); pr += __shfl_down(pr, off); ht += __shfl_down(ht, off); tx += __shfl_down(tx, off); tc += __shfl_down(tc, off); }
+        if (stats) { nd += __shfl_down(nd, off); tr += __shfl_down(tr, off); pr += __shfl_down(pr, off); ht += __shfl_down(ht, off); tx += __shfl_down(tx, off); tc += __shfl_down(tc, off); nf += __shfl_down(nf, off); }
     }
 #ifdef NR_PHASE_TIMING
     unsigned pn = c.cyc_node, pl = c.cyc_leaf, pt = c.cyc_tri; // accumulators only advance in active lanes: take the max over the wave
@@ -104,6 +104,7 @@ __device__ __forceinline__ void flush_counters(DeviceCounters* ctr, const Cnt& c
             atomicAdd(&ctr->prim_tests, (unsigned long long)pr); atomicAdd(&ctr->hit_records, (unsigned long long)ht);
             atomicAdd(&ctr->tex_samples, (unsigned long long)tx);
             if (tc) atomicAdd(&ctr->rays_primary_traced, (unsigned long long)tc);
+            if (nf) atomicAdd(&ctr->node_fetches, (unsigned long long)nf);
         }
     }
 }
@@ -175,7 +176,15 @@ __global__ void __launch_bounds__(kBlock, OCC ? NR_OCC3_AS : waves_per_simd(FEAT
     st.lds0 = Stack::addr((lds_u32*)lds_stack);
     st.park = (lds_u32*)(lds_park + threadIdx.x);
     st.init();
-    Cnt cnt; cnt.node = cnt.tri = cnt.prim = cnt.hit = cnt.tex = cnt.shadow = cnt.refl = cnt.refr = cnt.max_depth = cnt.max_chain_nodes = cnt.traced = cnt.elided = 0;
+    // a launch that records its tile costs also records itself (DRender::cost_meta): its first wave brackets its lifetime with both clocks, every wave leaves its end tick
+    const bool rec_meta = R.tile_cost && R.cost_meta; // wave-uniform
+    uint32_t clk_c0 = 0u, clk_t0 = 0u;
+    if (rec_meta) {
+        const unsigned long long t_ = __builtin_amdgcn_s_memrealtime();
+        clk_c0 = (uint32_t)__builtin_readcyclecounter(); clk_t0 = (uint32_t)t_;
+        if (blockIdx.x == 0 && threadIdx.x == 0) R.cost_meta[0] = t_;
+    }
+    Cnt cnt; cnt.node = cnt.tri = cnt.prim = cnt.hit = cnt.tex = cnt.shadow = cnt.refl = cnt.refr = cnt.max_depth = cnt.max_chain_nodes = cnt.traced = cnt.elided = cnt.fetch = 0;
 #ifdef NR_PHASE_TIMING
     cnt.cyc_node = cnt.cyc_leaf = cnt.cyc_other = cnt.cyc_tri = 0; cnt.wv_node = cnt.ln_node = cnt.wv_tri = cnt.ln_tri = 0; cnt.cyc_closest0 = cnt.cyc_closestN = cnt.cyc_shadow = 0; cnt.wv_uni = 0; cnt.inq_node = cnt.inq_tri = 0; for (int k_ = 0; k_ < 8; ++k_) cnt.cyc_x[k_] = 0;
     unsigned long long twave = __builtin_readcyclecounter();
@@ -451,6 +460,12 @@ __global__ void __launch_bounds__(kBlock, OCC ? NR_OCC3_AS : waves_per_simd(FEAT
         w2[0] = dbg_work_ticks; w2[1] = R.dbg_mode == 5u ? dbg_slow_row : dbg_miss_ticks; w2[2] = dbg_row_ticks; w2[3] = (dbg_work_tiles & 0xffu) | ((dbg_miss_tiles & 0xffu) << 8) | ((dbg_rows & 0xffu) << 16) | ((dbg_longest_ticks >> 4) << 24);
     }
 #endif
+    if (rec_meta && (threadIdx.x & 63u) == 0u) { // every wave: its end tick, and its lifetime in both clocks (sums over the waves: the clock the launch ran at, weighted by wave time)
+        const unsigned long long t_ = __builtin_amdgcn_s_memrealtime();
+        atomicMax(&R.cost_meta[1], t_);
+        atomicAdd(&R.cost_meta[2], (unsigned long long)((uint32_t)__builtin_readcyclecounter() - clk_c0));
+        atomicAdd(&R.cost_meta[3], (unsigned long long)((uint32_t)t_ - clk_t0));
+    }
     flush_counters(ctr, cnt, STATS);
 }
 

@@ -118,6 +118,7 @@ constexpr unsigned long long kSaltPath = 2ULL, kSaltRefl = 0x100ULL, kSaltRefr =
 #endif
 struct Cnt {
     unsigned node, tri, prim, hit, tex;     // instrumented builds only
+    unsigned fetch;                         // instrumented: 128-byte node records this lane fetched (a wave-uniform visit is counted by its leading lane only)
     unsigned shadow, refl, refr;            // ray classes, always counted
     unsigned max_depth;                     // deepest trace depth reached by this lane
     unsigned max_chain_nodes;               // instrumented: most AABB tests in one pixel's chain
@@ -949,6 +950,7 @@ NR_DEV bool traverse(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, Hit&
                 const NodePlanes np = load_planes_uniform(S.nodes, ukey);
                 // SURVEY 8d counts AABB tests: only the boxes that exist (an absent child slot is not a test)
                 if (STATS) cnt.node += (unsigned)(ch.x != kEmptyChild) + (unsigned)(ch.y != kEmptyChild) + (unsigned)(ch.z != kEmptyChild) + (unsigned)(ch.w != kEmptyChild);
+                if (STATS && (int)__lane_id() == __ffsll((long long)__ballot(1)) - 1) cnt.fetch++; // one scalar fetch serves the wave
                 box_keys4(np, rf, btf, k0, k1, k2, k3);
                 if ((rf.bits & 7u)) zero_axis_cull((rf.bits & 7u), co, np, k0, k1, k2, k3);
                 c0 = ch.x; c1 = ch.y; c2 = ch.z; c3 = ch.w;
@@ -956,6 +958,7 @@ NR_DEV bool traverse(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, Hit&
                 const int4 ch = load_children(S.nodes, cur);
                 const NodePlanes np = load_planes(S.nodes, cur, rf);
                 if (STATS) cnt.node += (unsigned)(ch.x != kEmptyChild) + (unsigned)(ch.y != kEmptyChild) + (unsigned)(ch.z != kEmptyChild) + (unsigned)(ch.w != kEmptyChild);
+                if (STATS) cnt.fetch++;
                 box_keys4(np, rf, btf, k0, k1, k2, k3);
                 if ((rf.bits & 7u)) zero_axis_cull((rf.bits & 7u), co, np, k0, k1, k2, k3);
                 c0 = ch.x; c1 = ch.y; c2 = ch.z; c3 = ch.w;
@@ -1188,7 +1191,7 @@ NR_MAT_ATTR f4 material_compute(const DScene& S, Stack& st, const ShadeRec& m, R
                 filter = pre_filter;
             } else {
                 cnt.shadow++;
-                if (!STATS && NR_ELIDE_DARK && !S.no_elide && light_is_dark(ldir, normal, ray.d, no_spec)) { cnt.elided++; continue; }
+                if ((!STATS || (S.stats_elide & 1u)) && NR_ELIDE_DARK && !S.no_elide && light_is_dark(ldir, normal, ray.d, no_spec)) { cnt.elided++; continue; }
                 NR_TIC(tsq);
                 // kFeatPark: what the Phong terms below need of this hit waits in LDS while the shadow ray is traced (the values are the same
                 // bits afterwards; `in.n`, `point` and `ray.d` are the caller's objects, so its later uses read the reloaded registers too)
@@ -1333,7 +1336,7 @@ NR_DEV f3 shade_hit(const DScene& S, Stack& st, RayState& ray, uint32_t depth, u
     // analytic ones 1.5 % of the primitives frame (same log); a perfect mirror in such a scene is shaded as the reference shades it.
     float alpha_known = -1.0f;
     bool elide = false;
-    if (!STATS && NR_ELIDE_TRANSPARENT && (FEAT & kFeatAlphaShadow) && (FEAT & kFeatMesh) && !S.no_elide) {
+    if ((!STATS || (S.stats_elide & 2u)) && NR_ELIDE_TRANSPARENT && (FEAT & kFeatAlphaShadow) && (FEAT & kFeatMesh) && !S.no_elide) {
         const ShadeRec& sm = S.shade[node_id];
         if (((sm.flags >> 8) & 0xffu) == NRAYS_MAT_PHONG) {
             const bool mirror = sm.refl_mix == 1.0f; // (the same for a perfect mirror: its own term is obj.rgb * (weight * alpha * (1 - 1)))
@@ -1371,7 +1374,7 @@ NR_DEV f3 shade_hit(const DScene& S, Stack& st, RayState& ray, uint32_t depth, u
             pre = true;
             NR_TOC(cyc_x[3], tsh);
             NR_TIC(tsq);
-            if (!STATS && NR_ELIDE_DARK && !S.no_elide && light_is_dark(ldir, is.n, ray.d, no_specular(S.shade[node_id]))) { if (count_me) cnt.elided++; pre_lit = false; } // (as if shadowed: the sample's term is 0 either way)
+            if ((!STATS || (S.stats_elide & 1u)) && NR_ELIDE_DARK && !S.no_elide && light_is_dark(ldir, is.n, ray.d, no_specular(S.shade[node_id]))) { if (count_me) cnt.elided++; pre_lit = false; } // (as if shadowed: the sample's term is 0 either way)
             else {
             // kFeatPark: the hit's record and the ray wait in LDS while the shadow ray is traced (the same bits come back)
             if ((FEAT & kFeatPark) && (FEAT & kFeatAlphaShadow)) {
