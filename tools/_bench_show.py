@@ -9,5 +9,7 @@ def show(n, m):
           "rec_ms", l.get("recording_launch_ms"), "valu", r.get("valu_active_frac"), "dram", r.get("dram_frac"), "kernel_ms", r["kernel_ms"], "cpu", m.get("cpu_baseline", {}).get("value"), m.get("gpu_over_cpu"), m.get("gpu_over_cpu_at_full_host"))
     print("   units", r["units_per_launch"]); print("   ref  ", r.get("reference_units_per_launch"))
 show("balls", d)
-for k, v in d.get("secondary", {}).items(): show(k, v)
+for k, v in d.get("secondary", {}).items():
+    if "roofline" in v: show(k, v)
+    else: print(k, json.dumps(v)[:1500])
 print(d.get("north_star_sponza"))
