@@ -1,9 +1,9 @@
-# tools/final_run.sh — the measurement pass behind profiles/r05_*final* (run through gpurun from the repo root):
+# tools/final_run.sh — the measurement pass behind profiles/r06_*final* (run through gpurun from the repo root):
 #   the default bench line; one `rocprofv3 --kernel-trace --stats` per workload over a steady-only run (balls, sponza, hairball, config 4, config 5), so that every
 #   roofline block's kernel time can be recomputed from profiles/r05_rocprofv3_kernel_stats_<scene>.csv; the counter passes; kbench / bigconfigs.
 set -x
 cd $GRAFT_REPO_ROOT
-R=r05
+R=r06
 mkdir -p gpurun_out/final
 timeout 1200 python bench.py > gpurun_out/final/${R}_bench_final.json 2> gpurun_out/final/bench.err; tail -c 400 gpurun_out/final/bench.err
 cd /tmp; export TMPDIR=/tmp
@@ -22,15 +22,17 @@ for s in balls sponza hairball; do timeout 500 python tools/pmc_collect.py $s gp
 timeout 400 python tools/kbench.py --scenes balls,ballsaway,primitives,sponza,sponza8,hairball --steps 30 > gpurun_out/final/${R}_kbench_final.log 2>&1
 timeout 600 python tools/bigconfigs.py > gpurun_out/final/${R}_bigconfigs.log 2>&1
 timeout 600 python tools/tile_scaling.py sponza8_4k 2>&1 | grep -v amdgpu.ids > gpurun_out/final/${R}_tile_scaling.log
+timeout 300 python tools/rank_bounds.py 2>&1 | grep world >> gpurun_out/final/${R}_tile_scaling.log
+for s in balls primitives sponza sponza8 hairball; do timeout 300 python tools/regimes.py $s 2>&1 | grep scene >> gpurun_out/final/${R}_regimes_final.log; done
 python - <<'PY'
 import json, csv, glob
-d=json.loads(open('gpurun_out/final/r05_bench_final.json').read().strip().splitlines()[-1])
+d=json.loads(open('gpurun_out/final/r06_bench_final.json').read().strip().splitlines()[-1])
 def show(n, m):
     r=m['roofline']; print(n, m['value'], m['ms_per_step'], r.get('kernel_ms'), r.get('kernel_ms_events'), r['frac'], r['bound'], r.get('dram_frac'), r.get('valu_active_frac'), m.get('cpu_baseline',{}).get('value'), m.get('gpu_over_cpu'), m.get('gpu_over_cpu_at_full_host'))
 show('balls', d)
 for k,v in d.get('secondary',{}).items(): show(k, v)
 print(d.get('north_star_sponza'))
-for f in sorted(glob.glob('gpurun_out/final/r05_rocprofv3_kernel_stats_*.csv')):
+for f in sorted(glob.glob('gpurun_out/final/r06_rocprofv3_kernel_stats_*.csv')):
     rows=[r for r in csv.DictReader(open(f)) if 'k_primary' in r['Name'] or 'k_resolve' in r['Name']]
     print(f.split('stats_')[-1], [(r['Name'][:48], r['Calls'], round(float(r['AverageNs'])/1e3,2)) for r in rows[:3]])
 PY
