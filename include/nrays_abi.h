@@ -264,9 +264,9 @@ typedef struct NraysTileCosts {
     uint64_t max_cycles;     /* the longest unit the schedule deals: a tile, or ONE PART of a split tile (light-parallel / pixel-split parts) */
     uint64_t resident_waves; /* waves of the persistent grid that rendered the frame */
     double shader_clock_hz;  /* the clock those cycles tick at, MEASURED by the launches that recorded them: s_memtime over s_memrealtime (100 MHz), summed over the
-                                lifetimes of all their waves */
-    double kernel_ms;        /* duration of that launch: first wave's start to the last wave's end (s_memrealtime).  max_cycles / shader_clock_hz and
-                                sum_cycles / resident_waves / shader_clock_hz are both <= kernel_ms: units and time come from the same launch */
+                                lifetimes of a sample of their waves */
+    double kernel_ms;        /* duration of that launch (HIP events of its own around it).  max_cycles / shader_clock_hz and sum_cycles / resident_waves /
+                                shader_clock_hz are fractions of kernel_ms: units and time come from the same launch */
 } NraysTileCosts;
 int nrays_get_tile_costs(NraysScene* scene, NraysTileCosts* out);
 

@@ -232,10 +232,8 @@ struct DRender {
     // Mesh scenes (dynamic dequeue): per-wave-tile cost of this frame (written) and the wave tiles in
     // descending order of the previous frame's cost (read; null = image order).  Scheduling only.
     uint32_t* tile_cost;
-    // ... and, with it, four words about the recording launch itself (nrays_get_tile_costs): [0] 100 MHz tick (s_memrealtime) at which its first wave started, [1] latest tick at
-    // which one of its waves ended (atomicMax: the counter is monotonic, no clearing), [2] shader cycles (s_memtime) and [3] ticks of ALL wave lifetimes, summed over the
-    // handle's recording launches (never cleared: the ratio is the clock the waves ran at, weighted by wave time) — the launch's duration and the clock its cycle counts
-    // tick at, measured by the launches that produced them
+    // ... and, with it, the clock those cycles tick at: [2] shader cycles (s_memtime) and [3] 100 MHz ticks (s_memrealtime) over the lifetimes of a sample of the launch's
+    // waves, summed over the handle's recording launches (never cleared: the ratio is the clock, weighted by wave time); [0], [1] unused
     unsigned long long* cost_meta;
 #ifdef NR_DEBUG_TILE_COSTS
     uint32_t dbg_mode;    // tuning builds: 1 = wave_times[1] holds the wave's work-tile cycles / 16 (26 bits) and its number of work tiles (6 bits)

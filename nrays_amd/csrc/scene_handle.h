@@ -51,6 +51,7 @@ struct NraysScene {
     // previous frame's wave-tile costs (k_primary) and the order derived from them (k_tile_order); valid for one
     // (width, rows, band) geometry at a time
     uint32_t* d_tile_cost = nullptr; uint32_t* d_tile_order = nullptr; uint32_t tile_slots = 0;
+    hipEvent_t ev_rec[2] = {nullptr, nullptr}; bool rec_events_valid = false; int rec_slot = -1; // around the last primary launch that recorded tile costs (NraysTileCosts::kernel_ms)
     unsigned long long* d_cost_meta = nullptr; // DRender::cost_meta: start / end ticks and the measured clock of the launch that recorded d_tile_cost
     // light-parallel tiles: log2 of the lanes per pixel (0 = the scene is not eligible), the split threshold in units of the frame's
     // work per resident wave (NRAYS_LIGHT_SPLIT: 0 = never, < 0 = every tile, default 1), the lengths of the eight lists
