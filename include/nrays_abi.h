@@ -263,8 +263,8 @@ typedef struct NraysTileCosts {
     uint64_t sum_cycles;     /* shader cycles (s_memtime) the waves spend on them (every part of a tile the cost-ordered lists split counted) */
     uint64_t max_cycles;     /* the longest unit the schedule deals: a tile, or ONE PART of a split tile (light-parallel / pixel-split parts) */
     uint64_t resident_waves; /* waves of the persistent grid that rendered the frame */
-    double shader_clock_hz;  /* the clock those cycles tick at, MEASURED by the launches that recorded them: s_memtime over s_memrealtime (100 MHz), summed over the
-                                lifetimes of a sample of their waves */
+    double shader_clock_hz;  /* the shader clock under this scene's load, MEASURED by the handle's instrumented launches (nrays_render_device_instrumented / _counted):
+                                s_memtime over s_memrealtime (100 MHz), summed over the lifetimes of a sample of their waves; 0 before the first such launch */
     double kernel_ms;        /* duration of that launch (HIP events of its own around it).  max_cycles / shader_clock_hz and sum_cycles / resident_waves /
                                 shader_clock_hz are fractions of kernel_ms: units and time come from the same launch */
 } NraysTileCosts;

@@ -188,7 +188,8 @@ struct DScene {
     uint32_t stats_elide;         // instrumented renders (set per launch): bit 0 = skip dark light samples, bit 1 = skip the shading of hits without a term of their own, as the
                                   // scene's PLAIN kernel does (NRAYS_COUNT_AS_TIMED); 0 = trace everything the reference traces
     uint32_t no_elide;            // some light / material / RGBA32F texel of the scene is not finite (or a shininess is negative): x * 0 is then not 0 for every x the
-                                  // reference multiplies, so NO shadow ray or Phong evaluation is skipped (light_is_dark(), shade_hit()); nrays_scene_create decides
+                                  // reference multiplies, so NO shadow ray or Phong evaluation may be skipped: nrays_scene_create decides, and the host renders such a
+                                  // scene's plain frames with the instrumented kernel (stats_elide = 0), which skips nothing
     // Small analytic scenes (no meshes; all records below within kLdsSceneBytes): one packed copy of nodes, instances,
     // links, shading records, node AABBs, lights and plane lists, which the kFeatLdsScene kernels stage into LDS once per
     // workgroup — a dependent record fetch then costs an LDS access instead of a trip through the vector memory path.
@@ -232,8 +233,8 @@ struct DRender {
     // Mesh scenes (dynamic dequeue): per-wave-tile cost of this frame (written) and the wave tiles in
     // descending order of the previous frame's cost (read; null = image order).  Scheduling only.
     uint32_t* tile_cost;
-    // ... and, with it, the clock those cycles tick at: [2] shader cycles (s_memtime) and [3] 100 MHz ticks (s_memrealtime) over the lifetimes of a sample of the launch's
-    // waves, summed over the handle's recording launches (never cleared: the ratio is the clock, weighted by wave time); [0], [1] unused
+    // The shader clock under this scene's load, measured by the handle's INSTRUMENTED launches: [2] shader cycles (s_memtime) and [3] 100 MHz ticks (s_memrealtime) over the
+    // lifetimes of a sample of their waves, summed (never cleared: the ratio is the clock, weighted by wave time); [0], [1] unused
     unsigned long long* cost_meta;
 #ifdef NR_DEBUG_TILE_COSTS
     uint32_t dbg_mode;    // tuning builds: 1 = wave_times[1] holds the wave's work-tile cycles / 16 (26 bits) and its number of work tiles (6 bits)

@@ -789,7 +789,8 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
     HIP_TRY(hipMemsetAsync(sc->d_wave_times, 0, (size_t)kMaxGrid * (kBlock / 64) * 8 * sizeof(uint32_t), stream));
     R.wave_times = sc->d_wave_times; sc->dbg_grid = grid_primary; R.dbg_mode = getenv("NRAYS_DEBUG_WAVE_WORK") ? (uint32_t)atoi(getenv("NRAYS_DEBUG_WAVE_WORK")) : 0u;
 #endif
-    if (R.tile_cost) { sc->cost_tiles = lane_log2 ? win_units : win_units * 4u; sc->cost_grid = grid_primary; sc->cost_split_lsl = R.light_lsl; R.cost_meta = sc->d_cost_meta; }
+    if (R.tile_cost) { sc->cost_tiles = lane_log2 ? win_units : win_units * 4u; sc->cost_grid = grid_primary; sc->cost_split_lsl = R.light_lsl; }
+    R.cost_meta = sc->d_cost_meta; // (read by the instrumented kernel only)
     bool first_primary = true;
     for (uint32_t s0 = 0; s0 < p->ray_per_pixel; s0 += batch) {
         R.sample_begin = s0; R.sample_end = std::min<uint32_t>(p->ray_per_pixel, s0 + batch);
@@ -805,11 +806,12 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
         if (first_primary && R.tile_cost) { sc->rec_events_valid = rec_events; sc->rec_slot = timed ? slot : -1; }
         if (rec_events) HIP_TRY(hipEventRecord(sc->ev_rec[0], stream));
         DScene dsc = sc->d;
-        if (instrumented && (count_flags & NRAYS_COUNT_AS_TIMED)) { // what the scene's plain kernel skips (trace_device.h: light_is_dark everywhere; shade_hit in the alpha-mapped mesh kernels)
+        if (instrumented && (count_flags & NRAYS_COUNT_AS_TIMED) && !sc->d.no_elide) { // what the scene's plain kernel skips (trace_device.h: light_is_dark everywhere; shade_hit in the alpha-mapped mesh kernels)
             const int f = primary_permutation_exists(sc->features & ~(int)kFeatLdsScene) ? sc->features : (int)kFeatAll; // the FEAT a plain frame of this scene is launched with
             dsc.stats_elide = 1u | (((f & kFeatMesh) && (f & kFeatAlphaShadow)) ? 2u : 0u);
         }
-        launch_primary(instrumented, sc->features, sc->noxform, sc->park, occ, grid_primary, stream, dsc, R, qo, d_out, sc->d_counters, sc->d_spill, tiles_x, tiles_y, sc->d_counts + kMaxGenerations + 2, grab, next_counts, R.first_batch ? next_ctr : nullptr);
+        // (a scene with a non-finite light / colour / texel: every frame by the kernel that skips nothing)
+        launch_primary(instrumented || sc->d.no_elide != 0u, sc->features, sc->noxform, sc->park, occ, grid_primary, stream, dsc, R, qo, d_out, sc->d_counters, sc->d_spill, tiles_x, tiles_y, sc->d_counts + kMaxGenerations + 2, grab, next_counts, R.first_batch ? next_ctr : nullptr);
         HIP_TRY(hipGetLastError());
         if (rec_events) HIP_TRY(hipEventRecord(sc->ev_rec[1], stream));
         if (first_primary) {
@@ -833,7 +835,7 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
             uint32_t grid = std::max<uint32_t>(std::min<uint32_t>((launch_n + kBlock - 1) / kBlock, kMaxGrid), std::min<uint32_t>((uint32_t)sc->num_cus, kMaxGrid));
             QueueOut qn; qn.q = sc->queue[(r + 1) & 1].q; qn.capacity = sc->queue_capacity; qn.count = sc->d_counts + r + 1;
             qn.overflow = &sc->d_counters->overflow;
-            if (instrumented) hipLaunchKernelGGL(k_bounce<true>, dim3(grid), dim3(kBlock), 0, stream, dsc, sc->queue[r & 1].q, sc->d_counts + r, sc->queue_capacity, qn, sc->d_fixed, sc->d_counters, sc->d_spill, p->max_depth);
+            if (instrumented || sc->d.no_elide) hipLaunchKernelGGL(k_bounce<true>, dim3(grid), dim3(kBlock), 0, stream, dsc, sc->queue[r & 1].q, sc->d_counts + r, sc->queue_capacity, qn, sc->d_fixed, sc->d_counters, sc->d_spill, p->max_depth);
             else hipLaunchKernelGGL(k_bounce<false>, dim3(grid), dim3(kBlock), 0, stream, sc->d, sc->queue[r & 1].q, sc->d_counts + r, sc->queue_capacity, qn, sc->d_fixed, sc->d_counters, sc->d_spill, p->max_depth);
             HIP_TRY(hipGetLastError());
             folded = false; sc->fixed_dirty = true;
@@ -961,6 +963,7 @@ int nrays_scene_create(const NraysSceneDesc* desc, NraysScene** out_scene) {
         for (int a = 0; a < 3; ++a) finite = finite && std::isfinite(h.background[a]);
         const char* e = getenv("NRAYS_ELIDE"); // =0: never (A/B)
         sc->d.no_elide = (!finite || (e && atoi(e) == 0)) ? 1u : 0u;
+        // (such a scene's frames are rendered by the instrumented kernel, which does not decode the split entries of a cost-ordered list: no light-parallel / pixel-split tiles — light_lsl stays 0 below)
     }
     std::vector<TextureRec> trecs;
     for (HostTexture& t : h.textures) {
@@ -1067,7 +1070,8 @@ int nrays_scene_create(const NraysSceneDesc* desc, NraysScene** out_scene) {
     if (const char* e = getenv("NRAYS_LPT")) sc->lpt_enabled = atoi(e) != 0;
     if (const char* e = getenv("NRAYS_SCREEN_CULL")) sc->cull_enabled = atoi(e) != 0;
     { const int f = sc->features; // multi-light mesh scenes without double branching: 2, 4 or 8 lanes per pixel in a split tile
-      if ((f & kFeatMultiSample) && (f & kFeatMesh) && !(f & kFeatDouble) && h.lights.size() >= 2) { uint32_t l = 1; while (l < 3u && (2u << l) <= h.lights.size()) ++l; sc->light_lsl = l; }
+      if (sc->d.no_elide) sc->light_lsl = 0;
+      else if ((f & kFeatMultiSample) && (f & kFeatMesh) && !(f & kFeatDouble) && h.lights.size() >= 2) { uint32_t l = 1; while (l < 3u && (2u << l) <= h.lights.size()) ++l; sc->light_lsl = l; }
       else if (NR_PIXEL_SPLIT && !(f & kFeatMultiSample) && (f & kFeatMesh) && (f & kFeatAlphaShadow) && !(f & kFeatDouble)) sc->light_lsl = 3; } // pixel split: 8 pixels per part
     if (const char* e = getenv("NRAYS_LIGHT_SPLIT")) sc->light_split_factor = (float)atof(e);
     if (const char* e = getenv("NRAYS_OCC")) sc->occ_override = atoi(e);

@@ -177,11 +177,11 @@ __global__ void __launch_bounds__(kBlock, OCC ? NR_OCC3_AS : waves_per_simd(FEAT
     st.park = (lds_u32*)(lds_park + threadIdx.x);
     st.init();
     // a launch that records its tile costs also records itself (DRender::cost_meta): its first wave brackets its lifetime with both clocks, every wave leaves its end tick
-    // a launch that records its tile costs also measures the clock they tick at (DRender::cost_meta): the first wave of every 32nd workgroup brackets its lifetime with
-    // both clocks.  (Every wave doing so — three atomics each on one line — cost the balls frame 0.062 -> 0.10 ms.)
-    const bool rec_meta = R.tile_cost && R.cost_meta && (blockIdx.x & 31u) == 0u && threadIdx.x < 64u; // wave-uniform
-    uint32_t clk_c0 = 0u, clk_t0 = 0u;
-    if (rec_meta) { clk_c0 = (uint32_t)__builtin_readcyclecounter(); clk_t0 = (uint32_t)__builtin_amdgcn_s_memrealtime(); }
+    // The instrumented kernel also measures the shader clock (DRender::cost_meta): the first wave of every 32nd workgroup brackets its lifetime with both clocks.  Not the
+    // plain kernels: every wave doing so in a cost-recording launch (three atomics each on one line) cost the balls frame 0.062 -> 0.10 ms, and even the sampled form's code
+    // 0.5 - 1 % of the analytic kernels' steady frames.
+    __shared__ uint32_t clk_start[STATS ? 2 : 1];
+    if (STATS && R.cost_meta && (blockIdx.x & 31u) == 0u && threadIdx.x == 0u) { clk_start[0] = (uint32_t)__builtin_readcyclecounter(); clk_start[1] = (uint32_t)__builtin_amdgcn_s_memrealtime(); }
     Cnt cnt; cnt.node = cnt.tri = cnt.prim = cnt.hit = cnt.tex = cnt.shadow = cnt.refl = cnt.refr = cnt.max_depth = cnt.max_chain_nodes = cnt.traced = cnt.elided = cnt.fetch = 0;
 #ifdef NR_PHASE_TIMING
     cnt.cyc_node = cnt.cyc_leaf = cnt.cyc_other = cnt.cyc_tri = 0; cnt.wv_node = cnt.ln_node = cnt.wv_tri = cnt.ln_tri = 0; cnt.cyc_closest0 = cnt.cyc_closestN = cnt.cyc_shadow = 0; cnt.wv_uni = 0; cnt.inq_node = cnt.inq_tri = 0; for (int k_ = 0; k_ < 8; ++k_) cnt.cyc_x[k_] = 0;
@@ -458,9 +458,9 @@ __global__ void __launch_bounds__(kBlock, OCC ? NR_OCC3_AS : waves_per_simd(FEAT
         w2[0] = dbg_work_ticks; w2[1] = R.dbg_mode == 5u ? dbg_slow_row : dbg_miss_ticks; w2[2] = dbg_row_ticks; w2[3] = (dbg_work_tiles & 0xffu) | ((dbg_miss_tiles & 0xffu) << 8) | ((dbg_rows & 0xffu) << 16) | ((dbg_longest_ticks >> 4) << 24);
     }
 #endif
-    if (rec_meta && threadIdx.x == 0u) { // lifetime in both clocks; sums over the sampled waves and over the handle's recording launches (never cleared: only the ratio is used)
-        atomicAdd(&R.cost_meta[2], (unsigned long long)((uint32_t)__builtin_readcyclecounter() - clk_c0));
-        atomicAdd(&R.cost_meta[3], (unsigned long long)((uint32_t)__builtin_amdgcn_s_memrealtime() - clk_t0));
+    if (STATS && R.cost_meta && (blockIdx.x & 31u) == 0u && threadIdx.x == 0u) { // lifetime in both clocks; sums over the sampled waves and over the handle's recording launches (never cleared: only the ratio is used)
+        atomicAdd(&R.cost_meta[2], (unsigned long long)((uint32_t)__builtin_readcyclecounter() - clk_start[0]));
+        atomicAdd(&R.cost_meta[3], (unsigned long long)((uint32_t)__builtin_amdgcn_s_memrealtime() - clk_start[STATS ? 1 : 0]));
     }
     flush_counters(ctr, cnt, STATS);
 }

@@ -1139,8 +1139,9 @@ NR_DEV bool shadow_query(const DScene& S, Stack& st, d3 o, d3 d, double tlimit, 
 // A material without a specular colour (Ks 0 0 0, most of an OBJ scene's materials): specular = ks * scoeff^shininess = 0 for every scoeff in (0, 1], and
 // diffuse + 0 = diffuse — the sample is dark as soon as the light is behind the surface.
 // Both elisions rest on x * 0 == 0 for every skipped x: nrays_scene_create checks that every light (position, radius, colour), material colour and RGBA32F texel
-// is finite and no shininess negative, and sets DScene::no_elide otherwise — such a scene is rendered as the reference renders it, NaN for NaN
-// (tests/test_elision_gpu.py).  `normal` and `dir` are unit vectors by construction (the casts return normalised normals, ncollide's contract; rays are normalised
+// is finite and no shininess negative, and sets DScene::no_elide otherwise — such a scene is rendered by the instrumented (STATS) kernel with stats_elide = 0, which
+// traces and shades everything the reference does, NaN for NaN (tests/test_elision_gpu.py); the plain kernels test nothing at run time (a scalar load and a branch in the
+// light loop cost the 8-light sponza frame 4 %).  `normal` and `dir` are unit vectors by construction (the casts return normalised normals, ncollide's contract; rays are normalised
 // where they are made), never scene input.
 NR_DEV bool light_is_dark(d3 ldir, d3 normal, d3 dir, bool no_specular) {
     const double dln = dot(ldir, normal);
@@ -1191,7 +1192,7 @@ NR_MAT_ATTR f4 material_compute(const DScene& S, Stack& st, const ShadeRec& m, R
                 filter = pre_filter;
             } else {
                 cnt.shadow++;
-                if ((!STATS || (S.stats_elide & 1u)) && NR_ELIDE_DARK && !S.no_elide && light_is_dark(ldir, normal, ray.d, no_spec)) { cnt.elided++; continue; }
+                if ((!STATS || (S.stats_elide & 1u)) && NR_ELIDE_DARK && light_is_dark(ldir, normal, ray.d, no_spec)) { cnt.elided++; continue; }
                 NR_TIC(tsq);
                 // kFeatPark: what the Phong terms below need of this hit waits in LDS while the shadow ray is traced (the values are the same
                 // bits afterwards; `in.n`, `point` and `ray.d` are the caller's objects, so its later uses read the reloaded registers too)
@@ -1336,7 +1337,7 @@ NR_DEV f3 shade_hit(const DScene& S, Stack& st, RayState& ray, uint32_t depth, u
     // analytic ones 1.5 % of the primitives frame (same log); a perfect mirror in such a scene is shaded as the reference shades it.
     float alpha_known = -1.0f;
     bool elide = false;
-    if ((!STATS || (S.stats_elide & 2u)) && NR_ELIDE_TRANSPARENT && (FEAT & kFeatAlphaShadow) && (FEAT & kFeatMesh) && !S.no_elide) {
+    if ((!STATS || (S.stats_elide & 2u)) && NR_ELIDE_TRANSPARENT && (FEAT & kFeatAlphaShadow) && (FEAT & kFeatMesh)) {
         const ShadeRec& sm = S.shade[node_id];
         if (((sm.flags >> 8) & 0xffu) == NRAYS_MAT_PHONG) {
             const bool mirror = sm.refl_mix == 1.0f; // (the same for a perfect mirror: its own term is obj.rgb * (weight * alpha * (1 - 1)))
@@ -1374,7 +1375,7 @@ NR_DEV f3 shade_hit(const DScene& S, Stack& st, RayState& ray, uint32_t depth, u
             pre = true;
             NR_TOC(cyc_x[3], tsh);
             NR_TIC(tsq);
-            if ((!STATS || (S.stats_elide & 1u)) && NR_ELIDE_DARK && !S.no_elide && light_is_dark(ldir, is.n, ray.d, no_specular(S.shade[node_id]))) { if (count_me) cnt.elided++; pre_lit = false; } // (as if shadowed: the sample's term is 0 either way)
+            if ((!STATS || (S.stats_elide & 1u)) && NR_ELIDE_DARK && light_is_dark(ldir, is.n, ray.d, no_specular(S.shade[node_id]))) { if (count_me) cnt.elided++; pre_lit = false; } // (as if shadowed: the sample's term is 0 either way)
             else {
             // kFeatPark: the hit's record and the ray wait in LDS while the shadow ray is traced (the same bits come back)
             if ((FEAT & kFeatPark) && (FEAT & kFeatAlphaShadow)) {

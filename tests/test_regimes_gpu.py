@@ -74,7 +74,8 @@ def test_counting_what_the_timed_kernel_does(gpu):
 
 
 def test_the_recording_launch_measures_itself(gpu):
-    """NraysTileCosts: duration and shader clock of the launch that recorded the tile costs; the longest unit and the sum per resident wave are fractions of THAT launch."""
+    """NraysTileCosts: duration of the launch that recorded the tile costs (its own events) and the shader clock under the scene's load (measured by instrumented launches);
+    the longest unit and the sum per resident wave are fractions of THAT launch."""
     import torch
     lib = abi.load_hip_lib()
     for make in (su.balls_scene, lambda: standins.sponza_scene(detail=0.3)):
@@ -83,6 +84,10 @@ def test_the_recording_launch_measures_itself(gpu):
         out = torch.empty((360, 640, 3), dtype=torch.float32, device="cuda")
         for _ in range(2):
             abi.check(lib.nrays_render_device(sc.device_handle(), C.byref(p), C.c_void_p(out.data_ptr()), None))
+        tc0 = abi.NraysTileCosts()
+        abi.check(lib.nrays_get_tile_costs(sc.device_handle(), C.byref(tc0)))
+        assert tc0.shader_clock_hz == 0.0 and tc0.kernel_ms > 0.0                   # the clock is measured by instrumented launches only (the plain kernels carry no code for it)
+        abi.check(lib.nrays_render_device_instrumented(sc.device_handle(), C.byref(p), C.c_void_p(out.data_ptr()), None))
         tc = abi.NraysTileCosts()
         abi.check(lib.nrays_get_tile_costs(sc.device_handle(), C.byref(tc)))
         assert tc.tiles > 0 and tc.kernel_ms > 0.0

@@ -14,6 +14,7 @@ for world in (1, 4, 8):
         rows = lib.nrays_tile_rows(C.byref(p))
         out = torch.empty((rows, full.width, 3), dtype=torch.float32, device="cuda")
         h = sc.device_handle()
+        abi.check(lib.nrays_render_device_instrumented(h, C.byref(p), C.c_void_p(out.data_ptr()), None))  # (measures the shader clock under this load)
         for _ in range(6): abi.check(lib.nrays_render_device(h, C.byref(p), C.c_void_p(out.data_ptr()), None))
         nr.get_stats(sc)
         for _ in range(4): abi.check(lib.nrays_render_device(h, C.byref(p), C.c_void_p(out.data_ptr()), None))
