@@ -3,7 +3,7 @@
   cold    the FIRST frame of a fresh handle (analytic scenes: image-order lists; mesh scenes: k_seed_costs' order)
   seed    k_seed_costs' guess for that frame (mesh scenes)
   exact   the frame that sorts the camera's own recorded costs (what a resting camera keeps)
-  moved   the same for the camera 8 bench-steps further along bench.py's moving path
+  moved1 / moved   the same for the cameras 1 and 8 bench-steps further along bench.py's moving path
 Needs a -DNR_DEBUG_TILE_COSTS build (exports nrays_debug_tile_costs / nrays_debug_seed_costs).
   NRAYS_HIP_LIB=nrays_amd/lib/v/tc.so python tools/tile_dump.py balls sponza"""
 import ctypes as C, json, os, sys
@@ -30,7 +30,7 @@ for name in sys.argv[1:] or ["balls"]:
     make = {"sponza": standins.sponza_scene, "hairball": standins.hairball_scene, "sponza8": lambda: standins.sponza_scene(n_lights=8),
             "balls": su.balls_scene, "primitives": lambda: su.primitives_scene(0.0, 1)}[name]
     res = {}
-    for tag, k in (("", 0), ("moved", 8)):
+    for tag, k in (("", 0), ("moved1", 1), ("moved", 8)):
         sc, cam = make()
         eye0 = np.array(cam["eye"], dtype=np.float64); at = np.array(cam["at"], dtype=np.float64)
         cam = dict(cam, eye=tuple(eye0 + k * 1e-3 * np.linalg.norm(eye0 - at) * np.array([1.0, 0.0, 0.0])))
@@ -45,7 +45,7 @@ for name in sys.argv[1:] or ["balls"]:
             seed = grab(lib.nrays_debug_seed_costs, h, n)
             if seed is not None: res["seed"] = seed
         abi.check(lib.nrays_render_device(h, C.byref(p), C.c_void_p(out.data_ptr()), None)); torch.cuda.synchronize()
-        res["moved" if tag else "exact"] = grab(lib.nrays_debug_tile_costs, h, n)
+        res[tag if tag else "exact"] = grab(lib.nrays_debug_tile_costs, h, n)
         res["waves"] = np.array([int(tc.resident_waves)])
     np.savez(os.path.join(ROOT, "gpurun_out", "r06", "tiles_%s.npz" % name), **res)
     print(json.dumps({"scene": name, "tiles": n, "keys": sorted(res)}), flush=True)
