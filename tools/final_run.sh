@@ -30,7 +30,8 @@ d=json.loads(open('gpurun_out/final/r06_bench_final.json').read().strip().splitl
 def show(n, m):
     r=m['roofline']; print(n, m['value'], m['ms_per_step'], r.get('kernel_ms'), r.get('kernel_ms_events'), r['frac'], r['bound'], r.get('dram_frac'), r.get('valu_active_frac'), m.get('cpu_baseline',{}).get('value'), m.get('gpu_over_cpu'), m.get('gpu_over_cpu_at_full_host'))
 show('balls', d)
-for k,v in d.get('secondary',{}).items(): show(k, v)
+for k,v in d.get('secondary',{}).items():
+    if 'roofline' in v: show(k, v)
 print(d.get('north_star_sponza'))
 for f in sorted(glob.glob('gpurun_out/final/r06_rocprofv3_kernel_stats_*.csv')):
     rows=[r for r in csv.DictReader(open(f)) if 'k_primary' in r['Name'] or 'k_resolve' in r['Name']]
