@@ -83,7 +83,9 @@ __device__ __forceinline__ void flush_counters(DeviceCounters* ctr, const Cnt& c
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { i0 += __shfl_down(i0, off); i1 += __shfl_down(i1, off); i2 += __shfl_down(i2, off); i3 += __shfl_down(i3, off); i4 += __shfl_down(i4, off); i5 += __shfl_down(i5, off); }
     if (__lane_id() == 0) {
+#ifndef NR_PT_SPLIT_MATERIAL // (tools/monster_probe.py builds: dbg2[6], [7] hold two more "outside the queries" buckets — opacity sample, material_compute — instead)
         atomicAdd(&ctr->dbg2[6], (unsigned long long)i4); atomicAdd(&ctr->dbg2[7], (unsigned long long)i5);
+#endif
         atomicAdd(&ctr->dbg[0], (unsigned long long)i0); atomicAdd(&ctr->dbg[1], (unsigned long long)i1);
         atomicAdd(&ctr->dbg[2], (unsigned long long)i2); atomicAdd(&ctr->dbg[3], (unsigned long long)i3);
         atomicAdd(&ctr->hit_records, (unsigned long long)pt);  // hit_records = triangle leaves (part of the leaf phases)

@@ -1347,6 +1347,9 @@ NR_DEV f3 shade_hit(const DScene& S, Stack& st, RayState& ray, uint32_t depth, u
             }
         }
     }
+#ifdef NR_PT_SPLIT_MATERIAL
+    NR_TOC(cyc_x[6], tsh); // shading record + opacity sample
+#endif
     if (elide) {
         if (count_me) { // the shadow rays the reference traces from this hit: one per light sample (light.rs:57-63)
             unsigned n = 0u;
@@ -1399,9 +1402,16 @@ NR_DEV f3 shade_hit(const DScene& S, Stack& st, RayState& ray, uint32_t depth, u
     const ShadeRec& sn = S.shade[node_id];
     d3 pt = ray.o + ray.d * hit.t;
     f4 obj;
+#ifdef NR_PT_SPLIT_MATERIAL
+    NR_TOC(cyc_x[4], tsh); // between the opacity sample / the shadow query and the material: in a divergent wave, the lanes that skip the shadow query WAIT here for the lanes that run it
+#endif
     if (elide) { obj.x = obj.y = obj.z = 0.0f; obj.w = alpha_known; }
     else obj = material_compute<STATS, FEAT>(S, st, sn, ray, pt, is, cnt, pre, pre_lit, pre_filter, lsl, alpha_known);
+#ifdef NR_PT_SPLIT_MATERIAL
+    NR_TOC(cyc_x[7], tsh); // material_compute
+#else
     NR_TOC(cyc_x[4], tsh);
+#endif
     bool may_recurse = depth < (uint32_t)kMaxGenerations && (max_depth == 0 || depth < max_depth);
     float mix = sn.refl_mix;
     float alpha = obj.w * sn.alpha;
