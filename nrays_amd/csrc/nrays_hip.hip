@@ -504,11 +504,17 @@ static int alloc_cost_stats(NraysScene* sc) {
 
 static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out, hipStream_t stream, bool instrumented, uint32_t count_flags = 0u) {
     if (!sc || !p || !d_out) return fail(NRAYS_ERR_BAD_ARG, "null argument");
+    // NRAYS_HOST_TIMES=1 (read by nrays_scene_create): microseconds of host time this call spends up to a few marks, for the handle's first frames (tools/cold_probe.py)
+    const bool host_times = sc->host_times && sc->frames_total < 4;
+    const unsigned long long ht_frame = sc->frames_total;
+    const auto ht0 = std::chrono::steady_clock::now();
+    auto ht = [&](const char* what) { if (host_times) fprintf(stderr, "  render_impl frame %llu: +%.1f us %s\n", ht_frame, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - ht0).count(), what); };
     if (p->ray_per_pixel == 0) return fail(NRAYS_ERR_BAD_ARG, "ray_per_pixel must be > 0 (scene.rs:37)");
     if (p->width == 0 || p->height == 0) return fail(NRAYS_ERR_BAD_ARG, "empty resolution");
     if (p->band_owners > 1 && (p->band_rows == 0 || p->band_owner >= p->band_owners)) return fail(NRAYS_ERR_BAD_ARG, "bad band parameters");
     HIP_TRY(hipSetDevice(sc->device));
 
+    ht("hipSetDevice");
     const uint32_t rows = tile_rows(p);
     const uint64_t npix_local = (uint64_t)rows * p->width;
     if (npix_local >= (1ull << 31)) return fail(NRAYS_ERR_UNSUPPORTED, "tile too large");
@@ -616,6 +622,7 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
             HIP_TRY(hipStreamWaitEvent(stream, sc->ev_switch, 0));
         }
     }
+    ht("parameters, screen bounds, window");
     const bool timed = instrumented || (sc->frames_total % sc->event_stride) == 0;
     sc->frames_total++;
     const int slot = (int)(sc->frames_recorded % NraysScene::kRing);
@@ -791,6 +798,7 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
 #endif
     if (R.tile_cost) { sc->cost_tiles = lane_log2 ? win_units : win_units * 4u; sc->cost_grid = grid_primary; sc->cost_split_lsl = R.light_lsl; }
     R.cost_meta = sc->d_cost_meta; // (read by the instrumented kernel only)
+    ht("scheduling state (seed / sort launches)");
     bool first_primary = true;
     for (uint32_t s0 = 0; s0 < p->ray_per_pixel; s0 += batch) {
         R.sample_begin = s0; R.sample_end = std::min<uint32_t>(p->ray_per_pixel, s0 + batch);
@@ -801,6 +809,7 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
         QueueOut qo; qo.q = sc->queue[1].q; qo.capacity = queued ? sc->queue_capacity : 0; qo.count = sc->d_counts + 1;
         qo.overflow = &sc->d_counters->overflow;
         if (first_primary && timed) HIP_TRY(hipEventRecord(sc->ev_pbegin[slot], stream));
+        if (first_primary) ht("event record before the launch");
         // a launch that records its tile costs is timed (nrays_get_tile_costs: NraysTileCosts::kernel_ms): by the ring's events when the frame has them, by a pair of its own otherwise
         const bool rec_events = first_primary && R.tile_cost && !timed && sc->ev_rec[0] && sc->ev_rec[1];
         if (first_primary && R.tile_cost) { sc->rec_events_valid = rec_events; sc->rec_slot = timed ? slot : -1; }
@@ -813,6 +822,7 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
         // (a scene with a non-finite light / colour / texel: every frame by the kernel that skips nothing)
         launch_primary(instrumented || sc->d.no_elide != 0u, sc->features, sc->noxform, sc->park, occ, grid_primary, stream, dsc, R, qo, d_out, sc->d_counters, sc->d_spill, tiles_x, tiles_y, sc->d_counts + kMaxGenerations + 2, grab, next_counts, R.first_batch ? next_ctr : nullptr);
         HIP_TRY(hipGetLastError());
+        if (first_primary) ht("k_primary launch");
         if (rec_events) HIP_TRY(hipEventRecord(sc->ev_rec[1], stream));
         if (first_primary) {
             if (timed) HIP_TRY(hipEventRecord(sc->ev_pend[slot], stream));
@@ -861,6 +871,7 @@ static int render_impl(NraysScene* sc, const NraysRenderParams* p, float* d_out,
         sc->frames_recorded++;
     }
     sc->last_stream = stream; sc->have_last = true;
+    ht("end (event records after the launch)");
     // owned rows only (padding rows of the last band carry no rays)
     uint64_t owned_rows = 0;
     if (p->band_rows == 0 || p->band_owners <= 1) owned_rows = p->height;
@@ -1085,6 +1096,7 @@ int nrays_scene_create(const NraysSceneDesc* desc, NraysScene** out_scene) {
     // 0.0565 at 16 / 64, 0.0550 with an order that is never refreshed; 0.049 at rest).
     sc->near_pixels = sc->host.any_mesh ? kNearPixels : 2.0 * kNearPixels; sc->max_order_age = sc->host.any_mesh ? 0u : 16u;
     if (const char* e = getenv("NRAYS_SPLIT_HYST")) sc->split_hyst = (float)atof(e);
+    sc->host_times = getenv("NRAYS_HOST_TIMES") != nullptr;
     if (const char* e = getenv("NRAYS_NEAR_PIXELS")) sc->near_pixels = atof(e);
     if (const char* e = getenv("NRAYS_ORDER_AGE")) sc->max_order_age = (uint32_t)std::max(0, atoi(e));
     if (const char* e = getenv("NRAYS_LEAD_WGS")) sc->lead_mode = atoi(e) != 0;

@@ -65,6 +65,7 @@ struct NraysScene {
     // ... and by cameras NEAR the one whose costs it was sorted from (nrays_hip.hip: cam_shift_px) for up to kMaxOrderAge frames, so that a moving camera does not
     // record and sort on every frame.  order_seeded: the order comes from k_seed_costs' guess, the next frame replaces it.
     nrays::CamSnap cost_snap, order_snap; bool order_seeded = false;
+    bool host_times = false;                        // NRAYS_HOST_TIMES: render_impl prints where the host time of a handle's first frames goes
     bool near_reuse = true;                         // NRAYS_NEAR_REUSE=0: only the very same camera reuses an order (A/B)
     double near_pixels = 16.0; uint32_t max_order_age = 8; // NRAYS_NEAR_PIXELS / NRAYS_ORDER_AGE
     float split_hyst = 0.5f;                        // NRAYS_SPLIT_HYST: a tile that ran in parts stays split down to this fraction of the split threshold (k_tile_order)
