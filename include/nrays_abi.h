@@ -202,7 +202,7 @@ typedef struct NraysStats {
 /* Threading contract of a scene handle: the library is re-entrant on DISTINCT handles (any threads, any streams).
  * ONE handle must not be used by two threads at the same time (its calls must be serialised by the caller); its
  * renders execute in call order — a render enqueued on another stream than its predecessor is ordered behind it by
- * the library — because the handle owns per-frame device state (counters, continuation queues, raygen tables, tile
+ * the library — because the handle owns per-frame device state (counters, continuation queues, per-camera scheduling state, tile
  * costs).  The environment switches NRAYS_MAX_PRIMARY / NRAYS_GRAB / NRAYS_LPT (tests and A/B runs) are read once,
  * by nrays_scene_create. */
 typedef struct NraysScene NraysScene; /* opaque */
