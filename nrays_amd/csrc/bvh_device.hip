@@ -276,9 +276,16 @@ struct SplitFrame { ClipPoly poly; PrimBounds box; int slot; int depth; };
 enum { kModeHist = 1, kModeEmit = 2 }; // count the extra references of every triangle (+ the histogram of their empty areas) / write the boxes
 // One thread walks the split tree of one triangle exactly like split_rec() of scene_build.cpp (low half first; the high half's
 // reference slot is reserved when the split happens).  kModeHist counts and files the empty area of every split; kModeEmit writes boxes.
+// One walk (round 6): a counting pass (kModeHist) also KEEPS the pieces it finds — the unsplit piece of triangle t in base_box[t], every extra piece as (box, t, slot) in this
+// workgroup's region of an unordered list (`u`: an LDS cursor hands out the places) — so that once the prefix sum over the counts is known k_place_extra moves them to where
+// kModeEmit's second walk would have written them (reference n + offsets[t] + slot: the same arrays, bit for bit) and the split trees are not walked again.  Only the LAST
+// counting pass's list is used (every pass starts its regions afresh); a region that overflows sets u_count[gridDim.x] and the host falls back to the second walk.
+struct PieceList { float* box; uint32_t* key; float* base_box; uint32_t* count; uint32_t region_cap; }; // box: 6 floats, key: (t, slot) per piece; count[wg], count[grid] = overflow
 template <int MODE>
 __global__ __launch_bounds__(256) void k_presplit(const TriRec* recs, const float* tbox, uint32_t n, double thr, int depth_cap, SplitFrame* frames, uint32_t* counts,
-                                                  const uint32_t* offsets, uint32_t* hist, float* ref_box, uint32_t* ref_tri, uint32_t* capped) {
+                                                  const uint32_t* offsets, uint32_t* hist, float* ref_box, uint32_t* ref_tri, uint32_t* capped, PieceList u) {
+    __shared__ uint32_t u_cursor;
+    if (MODE == kModeHist && u.box) { if (threadIdx.x == 0) u_cursor = 0u; __syncthreads(); }
     SplitFrame* stack = frames + (size_t)(blockIdx.x * 256u + threadIdx.x) * (kSplitDepthMax + 1);
     for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < n; t += gridDim.x * 256u) {
         ClipPoly cur; PrimBounds box; int slot = -1, depth = 0, sp = 0, next = 0;
@@ -295,6 +302,17 @@ __global__ __launch_bounds__(256) void k_presplit(const TriRec* recs, const floa
                     const size_t r = slot < 0 ? (size_t)t : (size_t)n + offsets[t] + (uint32_t)slot;
                     for (int a = 0; a < 3; ++a) { ref_box[6 * r + a] = box.mn[a]; ref_box[6 * r + 3 + a] = box.mx[a]; }
                     ref_tri[r] = t;
+                }
+                if (MODE == kModeHist && u.box) { // keep the piece (see PieceList)
+                    if (slot < 0) { for (int a = 0; a < 3; ++a) { u.base_box[6 * (size_t)t + a] = box.mn[a]; u.base_box[6 * (size_t)t + 3 + a] = box.mx[a]; } }
+                    else {
+                        const uint32_t pos = atomicAdd(&u_cursor, 1u);
+                        if (pos < u.region_cap) {
+                            const size_t q = (size_t)blockIdx.x * u.region_cap + pos;
+                            for (int a = 0; a < 3; ++a) { u.box[6 * q + a] = box.mn[a]; u.box[6 * q + 3 + a] = box.mx[a]; }
+                            u.key[2 * q] = t; u.key[2 * q + 1] = (uint32_t)slot;
+                        }
+                    }
                 }
                 if (sp == 0) break;
                 --sp;
@@ -316,6 +334,21 @@ __global__ __launch_bounds__(256) void k_presplit(const TriRec* recs, const floa
             box = bl; ++depth;
         }
         if (MODE != kModeEmit) counts[t] = (uint32_t)next;
+    }
+    if (MODE == kModeHist && u.box) {
+        __syncthreads();
+        if (threadIdx.x == 0) { u.count[blockIdx.x] = u_cursor < u.region_cap ? u_cursor : u.region_cap; if (u_cursor > u.region_cap) u.count[gridDim.x] = 1u; }
+    }
+}
+// The kept extra pieces to their final places: reference n + offsets[t] + slot (what kModeEmit computes while it walks).
+__global__ __launch_bounds__(256) void k_place_extra(PieceList u, const uint32_t* __restrict__ offsets, uint32_t n, float* __restrict__ ref_box, uint32_t* __restrict__ ref_tri) {
+    const uint32_t cnt = u.count[blockIdx.x];
+    for (uint32_t i = threadIdx.x; i < cnt; i += 256u) {
+        const size_t q = (size_t)blockIdx.x * u.region_cap + i;
+        const uint32_t t = u.key[2 * q], slot = u.key[2 * q + 1];
+        const size_t r = (size_t)n + offsets[t] + slot;
+        for (int a = 0; a < 6; ++a) ref_box[6 * r + a] = u.box[6 * q + a];
+        ref_tri[r] = t;
     }
 }
 __global__ void k_iota_refs(uint32_t n, const float* tbox, float* ref_box, uint32_t* ref_tri) {
@@ -887,8 +920,14 @@ int build_impl(const std::vector<DeviceMeshPart>& parts, const DeviceBuildOption
     const bool may_split = opt.presplit && n >= 64 && opt.budget > 0.0;
     const size_t frame_count = may_split ? (size_t)split_grid * 256u * (kSplitDepthMax + 1) : 1u;
     const size_t scan_bytes = ((n + 1 + kScanBlock - 1) / kScanBlock) * sizeof(uint32_t); // block sums of the prefix sum over the per-triangle reference counts (exclusive_scan_u32)
+    // one-walk pre-splitting: the pieces of the last counting pass are kept (PieceList): 1.25 x the larger budget in all, dealt to the workgroups' regions (their triangles are
+    // a uniform sample of the mesh); NRAYS_PRESPLIT_ONE_WALK=0: walk twice as before (A/B)
+    const bool one_walk = may_split && !(getenv("NRAYS_PRESPLIT_ONE_WALK") && atoi(getenv("NRAYS_PRESPLIT_ONE_WALK")) == 0);
+    const uint32_t region_cap = one_walk ? (uint32_t)((size_t)(1.25 * std::max(opt.budget, opt.budget_hairy) * (double)n) / split_grid + 1024u) : 0u;
+    const size_t u_pieces = (size_t)region_cap * split_grid;
     bytes1 += padded<TriRec>(n) + padded<TriUv>(n) + padded<float>(6 * n) + 2 * padded<double>(nblocks_tri) + padded<Counters>(1) + 2 * padded<uint32_t>(n + 1) +
               padded<uint32_t>(kHistBins) + padded<SplitFrame>(frame_count) + padded<char>(scan_bytes) + padded<PartDev>(parts.size()) + 4096;
+    if (one_walk) bytes1 += padded<float>(6 * u_pieces) + padded<uint32_t>(2 * u_pieces) + padded<float>(6 * n) + padded<uint32_t>(split_grid + 1u);
     DB_TRY(a1.reserve(bytes1));
     sw.lap("allocation (phase 1)");
     {   // A merged group (the sponza stand-in: 270 meshes under one isometry, ~800 small arrays) paid one synchronous hipMemcpy per array — 4-5 ms of
@@ -931,6 +970,11 @@ int build_impl(const std::vector<DeviceMeshPart>& parts, const DeviceBuildOption
     void* scan_tmp1 = a1.take<char>(scan_bytes + 16);
     PartDev* dparts = a1.take<PartDev>(parts.size());
     if (!frames || !scan_tmp1 || !dparts) { err = "device BLAS build: arena overflow (phase 1)"; return NRAYS_ERR_OOM; }
+    PieceList pieces; pieces.box = nullptr; pieces.key = nullptr; pieces.base_box = nullptr; pieces.count = nullptr; pieces.region_cap = region_cap;
+    if (one_walk) {
+        pieces.box = a1.take<float>(6 * u_pieces); pieces.key = a1.take<uint32_t>(2 * u_pieces); pieces.base_box = a1.take<float>(6 * n); pieces.count = a1.take<uint32_t>(split_grid + 1u);
+        if (!pieces.count) { err = "device BLAS build: arena overflow (phase 1, piece list)"; return NRAYS_ERR_OOM; }
+    }
     sw.lap("upload of the mesh arrays");
     Counters h_ctr; std::memset(&h_ctr, 0, sizeof h_ctr);
     for (int k = 0; k < 6; ++k) { h_ctr.bounds[k] = 0xffffffffu; h_ctr.bounds[6 + k] = 0u; }
@@ -981,7 +1025,8 @@ int build_impl(const std::vector<DeviceMeshPart>& parts, const DeviceBuildOption
         auto pass = [&](double t, int cap) -> int {
             DB_TRY(hipMemset(hist, 0, kHistBins * sizeof(uint32_t)));
             DB_TRY(hipMemset(capped, 0, 4));
-            hipLaunchKernelGGL(k_presplit<kModeHist>, dim3(split_grid), dim3(256), 0, 0, recs, tbox, (uint32_t)n, t, cap, frames, counts, offsets, hist, (float*)nullptr, (uint32_t*)nullptr, capped);
+            if (pieces.count) DB_TRY(hipMemset(pieces.count + split_grid, 0, 4)); // the overflow mark of this pass's piece list
+            hipLaunchKernelGGL(k_presplit<kModeHist>, dim3(split_grid), dim3(256), 0, 0, recs, tbox, (uint32_t)n, t, cap, frames, counts, offsets, hist, (float*)nullptr, (uint32_t*)nullptr, capped, pieces);
             DB_TRY(exclusive_scan_u32(counts, offsets, (uint32_t)(n + 1), (uint32_t*)scan_tmp1));
             DB_TRY(hipMemcpy(&extra, offsets + n, 4, hipMemcpyDeviceToHost));
             return NRAYS_OK;
@@ -1005,6 +1050,11 @@ int build_impl(const std::vector<DeviceMeshPart>& parts, const DeviceBuildOption
         }
         if ((size_t)extra > 2 * budget + 1024) { err = "device BLAS build: pre-splitting does not settle on its budget"; return NRAYS_ERR_HIP; }
         nrefs = n + extra; do_split = extra > 0;
+        if (pieces.count) { // did the last pass's pieces fit their regions?
+            uint32_t over = 0;
+            DB_TRY(hipMemcpy(&over, pieces.count + split_grid, 4, hipMemcpyDeviceToHost));
+            if (over) { pieces.box = nullptr; if (verbose) fprintf(stderr, "  device build: piece list overflow, the split trees are walked a second time\n"); }
+        }
     }
     out.hairy = hairy;
     if (nrefs + (size_t)prim_base >= (1u << 28)) { err = "too many triangles"; return NRAYS_ERR_UNSUPPORTED; }
@@ -1027,7 +1077,11 @@ int build_impl(const std::vector<DeviceMeshPart>& parts, const DeviceBuildOption
     uint32_t* chunk_task = a2.take<uint32_t>(max_c); uint32_t* chunk_off = a2.take<uint32_t>(max_c); uint32_t* scan_tmp = a2.take<uint32_t>(max_c); uint32_t* chunk_lefts = a2.take<uint32_t>(max_c);
     uint32_t* chunk_cnt = a2.take<uint32_t>(max_c * 96u);
     if (!chunk_cnt) { err = "device BLAS build: arena overflow (phase 2)"; return NRAYS_ERR_OOM; }
-    if (do_split) hipLaunchKernelGGL(k_presplit<kModeEmit>, dim3(split_grid), dim3(256), 0, 0, recs, tbox, (uint32_t)n, thr, kSplitDepthMax, frames, counts, offsets, hist, ref_box, ref_tri, (uint32_t*)nullptr);
+    if (do_split && pieces.box) { // one walk: the kept pieces to their places (k_iota_refs: reference t = the unsplit piece of triangle t)
+        hipLaunchKernelGGL(k_iota_refs, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, 0, (uint32_t)n, (const float*)pieces.base_box, ref_box, ref_tri);
+        hipLaunchKernelGGL(k_place_extra, dim3(split_grid), dim3(256), 0, 0, pieces, (const uint32_t*)offsets, (uint32_t)n, ref_box, ref_tri);
+    } else if (do_split) { PieceList none; none.box = nullptr; none.key = nullptr; none.base_box = nullptr; none.count = nullptr; none.region_cap = 0u;
+        hipLaunchKernelGGL(k_presplit<kModeEmit>, dim3(split_grid), dim3(256), 0, 0, recs, tbox, (uint32_t)n, thr, kSplitDepthMax, frames, counts, offsets, hist, ref_box, ref_tri, (uint32_t*)nullptr, none); }
     else hipLaunchKernelGGL(k_iota_refs, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, 0, (uint32_t)n, tbox, ref_box, ref_tri);
     sw.lap("reference boxes");
     const float prim_cost = hairy ? opt.prim_cost_hairy : opt.prim_cost;
