@@ -905,7 +905,8 @@ int build_impl(const std::vector<DeviceMeshPart>& parts, const DeviceBuildOption
     if (n == 0 || n >= (1u << 28)) { err = "device BLAS build: bad triangle count"; return NRAYS_ERR_BAD_ARG; }
     out.num_triangles = n;
     const uint32_t nblocks_tri = [&] { uint32_t b = 0; for (const DeviceMeshPart& p : parts) b += (p.num_triangles + 255u) / 256u; return b; }();
-    const uint32_t split_grid = (uint32_t)std::min<size_t>(512, (n + 255) / 256);
+    const uint32_t split_grid_max = getenv("NRAYS_SPLIT_GRID") ? (uint32_t)std::max(1, atoi(getenv("NRAYS_SPLIT_GRID"))) : 512u; // workgroups of k_presplit (each thread owns a 6.9 KB stack of frames)
+    const uint32_t split_grid = (uint32_t)std::min<size_t>(split_grid_max, (n + 255) / 256);
 
     // ---- phase 1: inputs, triangle records, pre-split counts ----
     std::map<const void*, std::pair<size_t, void*>> uploads; // host array -> (bytes, device copy): meshes alias their vertex arrays
