@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <chrono>
 #include <future>
 #include <thread>
@@ -492,6 +493,8 @@ int build_host_scene(const NraysSceneDesc* d, HostScene& out, std::string& err) 
     // ---- per-node records, opacity classification, transform groups ----------------------
     struct NodeInfo { double R[9]; bool identity; bool opaque; bool has_uv; bool no_uv_values; };
     std::vector<NodeInfo> info(d->num_nodes);
+    std::vector<uint32_t> pending_aabb;                       // TriMesh nodes whose local AABB comes from their device-built BLAS (below)
+    std::map<uint32_t, std::array<float, 6>> single_bounds;   // node -> local bounds of a device-built BLAS that holds this node alone
     float att_min = std::numeric_limits<float>::infinity();
     for (uint32_t i = 0; i < d->num_nodes; ++i) {
         const NraysNode& n = d->nodes[i];
@@ -533,6 +536,13 @@ int build_host_scene(const NraysSceneDesc* d, HostScene& out, std::string& err) 
         }
         {
             float mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
+            // A mesh large enough for the device builder gets its local AABB from that build (k_tri_records reduces the same f32 min / max over the faces' vertices and checks
+            // the indices): the host scan of the hairball stand-in's 8.6 M indices — random vertex reads — took 8 of its 100 ms.  Filled in below, once its BLAS exists.
+            if (n.shape_kind == NRAYS_SHAPE_TRIMESH && d->meshes[n.mesh_id].num_triangles >= device_build_min()) { // (NRAYS_GPU_BUILD=0: the minimum is SIZE_MAX)
+                pending_aabb.push_back(i);
+                out.node_aabbs.insert(out.node_aabbs.end(), 6, 0.0);
+                continue;
+            }
             if (n.shape_kind == NRAYS_SHAPE_TRIMESH) { // local AABB = union of the faces' vertices (TriMesh BVT root)
                 const NraysMesh& m = d->meshes[n.mesh_id];
                 for (int a = 0; a < 3; ++a) { mn[a] = std::numeric_limits<float>::infinity(); mx[a] = -std::numeric_limits<float>::infinity(); }
@@ -609,6 +619,7 @@ int build_host_scene(const NraysSceneDesc* d, HostScene& out, std::string& err) 
         uint32_t n0 = ids[0];
         auto add = [&](const std::vector<uint32_t>& sub, bool closest, bool shadow, bool anyhit, const Blas* reuse, Blas& blas) -> int {
             if (!reuse) { int rc = append_blas(d, sub, out, blas, err); if (rc != NRAYS_OK) return rc; } else blas = *reuse;
+            if (!reuse && sub.size() == 1 && blas.device) single_bounds[sub[0]] = std::array<float, 6>{blas.mn[0], blas.mn[1], blas.mn[2], blas.mx[0], blas.mx[1], blas.mx[2]};
             Instance in = base_instance(n0);
             in.flags &= ~(uint32_t)kInstSolid; // TriMesh ignores `solid` (SURVEY B-8)
             in.node_id = sub.size() == 1 ? (int32_t)sub[0] : -1;
@@ -633,6 +644,25 @@ int build_host_scene(const NraysSceneDesc* d, HostScene& out, std::string& err) 
             if (!opaque.empty()) { rc = add(opaque, false, true, true, nullptr, tmp); if (rc != NRAYS_OK) return rc; }
             for (uint32_t i : transp) { rc = add(std::vector<uint32_t>{i}, false, true, false, nullptr, tmp); if (rc != NRAYS_OK) return rc; }
         }
+    }
+
+    for (uint32_t i : pending_aabb) { // the local AABBs left open above: from the node's own device-built BLAS, else (merged groups, host fall-back) by the scan
+        const NraysNode& n = d->nodes[i];
+        const NraysMesh& m = d->meshes[n.mesh_id];
+        float mn[3], mx[3];
+        const auto it = single_bounds.find(i);
+        if (it != single_bounds.end()) { for (int a = 0; a < 3; ++a) { mn[a] = it->second[a]; mx[a] = it->second[3 + a]; } }
+        else {
+            for (int a = 0; a < 3; ++a) { mn[a] = std::numeric_limits<float>::infinity(); mx[a] = -std::numeric_limits<float>::infinity(); }
+            for (uint32_t t = 0; t < m.num_triangles * 3u; ++t) {
+                const uint32_t vi = m.indices[t];
+                if (vi >= m.num_vertices) { err = "triangle index out of range"; return NRAYS_ERR_BAD_ARG; }
+                for (int a = 0; a < 3; ++a) { const float f = (float)m.vertices[3 * (size_t)vi + a]; mn[a] = std::min(mn[a], f); mx[a] = std::max(mx[a], f); }
+            }
+        }
+        double bb[6];
+        node_world_aabb(n, info[i].R, mn, mx, bb);
+        for (int a = 0; a < 6; ++a) out.node_aabbs[6 * (size_t)i + a] = bb[a];
     }
 
     {   // kernel permutation: 1 = analytic shapes, 2 = meshes, 4 = some node may be non-opaque to shadow rays
