@@ -924,7 +924,9 @@ int build_impl(const std::vector<DeviceMeshPart>& parts, const DeviceBuildOption
     // one-walk pre-splitting: the pieces of the last counting pass are kept (PieceList): 1.25 x the larger budget in all, dealt to the workgroups' regions (their triangles are
     // a uniform sample of the mesh); NRAYS_PRESPLIT_ONE_WALK=0: walk twice as before (A/B)
     const bool one_walk = may_split && !(getenv("NRAYS_PRESPLIT_ONE_WALK") && atoi(getenv("NRAYS_PRESPLIT_ONE_WALK")) == 0);
-    const uint32_t region_cap = one_walk ? (uint32_t)((size_t)(1.25 * std::max(opt.budget, opt.budget_hairy) * (double)n) / split_grid + 1024u) : 0u;
+    // (NRAYS_DEBUG_PIECE_CAP=c: c places per region — tests: the regions overflow and the second walk takes over)
+    const uint32_t region_cap = !one_walk ? 0u : getenv("NRAYS_DEBUG_PIECE_CAP") ? (uint32_t)std::max(1, atoi(getenv("NRAYS_DEBUG_PIECE_CAP")))
+                                : (uint32_t)((size_t)(1.25 * std::max(opt.budget, opt.budget_hairy) * (double)n) / split_grid + 1024u);
     const size_t u_pieces = (size_t)region_cap * split_grid;
     bytes1 += padded<TriRec>(n) + padded<TriUv>(n) + padded<float>(6 * n) + 2 * padded<double>(nblocks_tri) + padded<Counters>(1) + 2 * padded<uint32_t>(n + 1) +
               padded<uint32_t>(kHistBins) + padded<SplitFrame>(frame_count) + padded<char>(scan_bytes) + padded<PartDev>(parts.size()) + 4096;

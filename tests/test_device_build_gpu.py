@@ -113,6 +113,25 @@ def test_presplit_on_the_device_matches_the_host_rule(gpu):
     assert np.array_equal(np.delete(h["nodes"], np.s_[8:12], axis=1), np.delete(d["nodes"], np.s_[8:12], axis=1))
 
 
+def test_presplit_in_one_walk_two_walks_and_after_an_overflow_is_one_tree(gpu, monkeypatch, capfd):
+    """Round 6: the counting pass of the pre-splitting keeps its pieces and k_place_extra moves them where the second walk (kModeEmit) would have written them.  The same
+    mesh built with the one walk, with NRAYS_PRESPLIT_ONE_WALK=0 (two walks), and with piece regions too small (NRAYS_DEBUG_PIECE_CAP: overflow -> the second walk takes over)
+    must give the same nodes and the same triangle behind every reference."""
+    pts, idx, _ = standins.hairball_geometry(strands=200, sides=6, segments=40)
+    one = _build(pts, idx, True, presplit=True)
+    assert one["hairy"] == 1 and len(one["tri"]) > 2 * len(idx)
+    monkeypatch.setenv("NRAYS_PRESPLIT_ONE_WALK", "0")
+    two = _build(pts, idx, True, presplit=True)
+    monkeypatch.delenv("NRAYS_PRESPLIT_ONE_WALK")
+    monkeypatch.setenv("NRAYS_DEBUG_PIECE_CAP", "3")
+    monkeypatch.setenv("NRAYS_BUILD_TIMES", "1")
+    over = _build(pts, idx, True, presplit=True)
+    assert "piece list overflow" in capfd.readouterr().err
+    for other in (two, over):
+        _same_tree(one, other)
+        assert np.array_equal(one["tri"], other["tri"])
+
+
 def test_bad_meshes_are_refused_like_on_the_host(gpu):
     pts, idx = _soup(100, 1)
     bad = idx.copy(); bad[50, 1] = 10**6
