@@ -132,10 +132,19 @@ def test_loader3d_cli_end_to_end(globe, tmp_path):
     p = nr.make_params((160, 90), 1, 0.0, cam["eye"], fs.inverse_projection(0, 160, 90))
     ref, _ = oracle.render(fs.descriptor, p, 8)
     pngs = []
-    for extra in ([], ["--gpus", "3"]):
+    for extra in (["--times"], ["--gpus", "3"]):
         r = subprocess.run([exe, scene, "--width", "160", "--height", "90"] + extra, cwd=str(tmp_path), capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-800:]
         assert "Rays cast." in r.stdout and "Image saved." in r.stdout
+        if "--times" in extra:  # the stage times behind bench.py's drop_in_end_to_end block: one JSON line, every stage present, the stages within the total
+            import json
+            line = [l for l in r.stdout.splitlines() if l.startswith('{"loader3d_times_ms"')]
+            assert len(line) == 1
+            t = json.loads(line[0])
+            ms = t["loader3d_times_ms"]
+            assert set(ms) == {"parse_scene_obj_mtl_textures", "dlopen_libnrays_hip", "nrays_scene_create_incl_hip_init", "render_cold_incl_d2h", "render_gpu_events", "quantise_encode_write_image", "total"}
+            assert t["cameras"] == 1 and t["rays"] > 160 * 90 and ms["render_gpu_events"] > 0.0
+            assert sum(v for k, v in ms.items() if k not in ("total", "render_gpu_events")) <= ms["total"] * 1.001
         pngs.append(open(str(tmp_path / "out.png"), "rb").read())
         os.remove(str(tmp_path / "out.png"))
     assert pngs[0] == pngs[1]  # tiling does not change a byte
