@@ -389,6 +389,23 @@ __global__ __launch_bounds__(1024) void k_chunk_scan(const Task* tasks, uint32_t
     if (threadIdx.x == 1023u) chunk_base[nt] = s_sum[1023];
 }
 
+// The same for the NEXT level, whose task count the host does not know yet: read from the device (Counters::n_next), handed back with the chunk total in out2 — ONE blocking
+// read-back per level instead of two (a level is ~110 us of which each read-back is ~25).  A count beyond the lists' capacity is only reported (the host fails the build).
+__global__ __launch_bounds__(1024) void k_chunk_scan_next(const Task* tasks, const uint32_t* nt_ptr, uint32_t cap, uint32_t* chunk_base, uint32_t* out2) {
+    __shared__ uint32_t s_sum[1024];
+    const uint32_t nt = *nt_ptr;
+    if (nt == 0u || nt > cap) { if (threadIdx.x == 0u) { out2[0] = nt; out2[1] = 0u; } return; } // (uniform)
+    const uint32_t per = (nt + 1023u) / 1024u, lo = threadIdx.x * per, hi = min(nt, lo + per);
+    uint32_t sum = 0;
+    for (uint32_t i = lo; i < hi; ++i) sum += (tasks[i].count + kChunk - 1u) / kChunk;
+    s_sum[threadIdx.x] = sum;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024u; off <<= 1) { uint32_t v = threadIdx.x >= off ? s_sum[threadIdx.x - off] : 0u; __syncthreads(); s_sum[threadIdx.x] += v; __syncthreads(); }
+    uint32_t run = s_sum[threadIdx.x] - sum;
+    for (uint32_t i = lo; i < hi; ++i) { chunk_base[i] = run; run += (tasks[i].count + kChunk - 1u) / kChunk; }
+    if (threadIdx.x == 1023u) { chunk_base[nt] = s_sum[1023]; out2[0] = nt; out2[1] = s_sum[1023]; }
+}
+
 __global__ __launch_bounds__(256) void k_bin(const Task* tasks, uint32_t nt, const uint32_t* chunk_base, uint32_t* chunk_task, const uint32_t* order0, const uint32_t* order1,
                                              const float* ref_box, uint32_t* gmn, uint32_t* gmx, uint32_t* gcnt, uint32_t* chunk_cnt) {
     __shared__ uint32_t smn[kBinWords], smx[kBinWords], scnt[96];
@@ -1079,7 +1096,8 @@ int build_impl(const std::vector<DeviceMeshPart>& parts, const DeviceBuildOption
     SplitInfo* split = a2.take<SplitInfo>(max_t); uint32_t* chunk_base = a2.take<uint32_t>(max_t + 1);
     uint32_t* chunk_task = a2.take<uint32_t>(max_c); uint32_t* chunk_off = a2.take<uint32_t>(max_c); uint32_t* scan_tmp = a2.take<uint32_t>(max_c); uint32_t* chunk_lefts = a2.take<uint32_t>(max_c);
     uint32_t* chunk_cnt = a2.take<uint32_t>(max_c * 96u);
-    if (!chunk_cnt) { err = "device BLAS build: arena overflow (phase 2)"; return NRAYS_ERR_OOM; }
+    uint32_t* level2 = a2.take<uint32_t>(2); // k_chunk_scan_next: {tasks, chunks} of the next level
+    if (!chunk_cnt || !level2) { err = "device BLAS build: arena overflow (phase 2)"; return NRAYS_ERR_OOM; }
     if (do_split && pieces.box) { // one walk: the kept pieces to their places (k_iota_refs: reference t = the unsplit piece of triangle t)
         hipLaunchKernelGGL(k_iota_refs, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, 0, (uint32_t)n, (const float*)pieces.base_box, ref_box, ref_tri);
         hipLaunchKernelGGL(k_place_extra, dim3(split_grid), dim3(256), 0, 0, pieces, (const uint32_t*)offsets, (uint32_t)n, ref_box, ref_tri);
@@ -1095,11 +1113,13 @@ int build_impl(const std::vector<DeviceMeshPart>& parts, const DeviceBuildOption
     hipLaunchKernelGGL(k_root_bounds, dim3(std::min<uint32_t>(1024u, (R + 255u) / 256u)), dim3(256), 0, 0, ref_box, R, order0, ctr);
     hipLaunchKernelGGL(k_root_task, dim3(1), dim3(1), 0, 0, tasks[0], small, R, ctr);
     uint32_t nt = R > kSmall ? 1u : 0u; int cur = 0, levels = 0;
+    uint32_t nchunks = 0;
+    if (nt > 0) { // the first level's chunks; every later level's come back with its task count (k_chunk_scan_next)
+        hipLaunchKernelGGL(k_chunk_scan, dim3(1), dim3(1024), 0, 0, tasks[cur], nt, chunk_base);
+        DB_TRY(hipMemcpy(&nchunks, chunk_base + nt, 4, hipMemcpyDeviceToHost));
+    }
     while (nt > 0) {
         if (nt > max_t) { err = "device BLAS build: task list overflow"; return NRAYS_ERR_HIP; }
-        hipLaunchKernelGGL(k_chunk_scan, dim3(1), dim3(1024), 0, 0, tasks[cur], nt, chunk_base);
-        uint32_t nchunks = 0;
-        DB_TRY(hipMemcpy(&nchunks, chunk_base + nt, 4, hipMemcpyDeviceToHost));
         if (nchunks == 0 || nchunks > max_c) { err = "device BLAS build: chunk list overflow"; return NRAYS_ERR_HIP; }
         DB_TRY(hipMemsetAsync(gmn, 0xff, (size_t)nt * kBinWords * 4u, 0));
         DB_TRY(hipMemsetAsync(gmx, 0, (size_t)nt * kBinWords * 4u, 0));
@@ -1111,7 +1131,10 @@ int build_impl(const std::vector<DeviceMeshPart>& parts, const DeviceBuildOption
         hipLaunchKernelGGL(k_chunk_lefts, dim3((nchunks + 255u) / 256u), dim3(256), 0, 0, chunk_task, chunk_cnt, split, nchunks, chunk_lefts);
         hipLaunchKernelGGL(k_part_scan, dim3(1), dim3(1024), 0, 0, chunk_task, chunk_base, chunk_lefts, nchunks, chunk_off, scan_tmp);
         hipLaunchKernelGGL(k_scatter, dim3(nchunks), dim3(256), 0, 0, tasks[cur], chunk_task, chunk_base, chunk_off, split, order0, order1, ref_box);
-        DB_TRY(hipMemcpy(&nt, &ctr->n_next, 4, hipMemcpyDeviceToHost));
+        hipLaunchKernelGGL(k_chunk_scan_next, dim3(1), dim3(1024), 0, 0, tasks[cur ^ 1], (const uint32_t*)&ctr->n_next, (uint32_t)max_t, chunk_base, level2);
+        uint32_t two[2] = {0u, 0u};
+        DB_TRY(hipMemcpy(two, level2, 8, hipMemcpyDeviceToHost));
+        nt = two[0]; nchunks = two[1];
         cur ^= 1; ++levels;
         if (levels > 4096) { err = "device BLAS build: the large-node phase does not end"; return NRAYS_ERR_HIP; }
     }
